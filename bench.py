@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- training samples/sec of the MLP mini-batch SGD path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one gradientStep (SCE:297-346: forward + backward + [all-reduce] + momentum update)
+on one batch of synthetic 784-dim inputs already resident in HBM.  The workload at every N is
+BASELINE.json configs[1] per GPU: 784-300-100-10, fp32, batch 128 per GPU (weak scaling: the
+global batch is 128*N, sharded by rows, ONE all-reduce(SUM) of the flat weight gradient per step
+over RCCL, identical update on every rank).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DIMS = [784, 300, 100, 10]
+BATCH = 128
+STEP, MOMENTUM = 0.0125, 0.9  # MT:227-229
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def synthetic(n, seed):
+    """X ~ U[0,1) 784-dim, uniform one-hot labels; generated here, never shipped."""
+    rng = np.random.default_rng(seed)
+    X = rng.random((n, DIMS[0]))
+    Y = np.eye(DIMS[-1])[rng.integers(0, DIMS[-1], n)]
+    return X, Y
+
+
+def cpu_baseline(seconds=12.0):
+    """The oracle (serial fp64 C restatement of the Java loop, NOT a JVM run) timed on one host
+    core on a bounded sample of the same workload.  Reported baseline only."""
+    from oracle import oracle
+    oracle.build()
+    net = oracle.OracleNet(DIMS)
+    X, Y = synthetic(BATCH * 4, 1234)
+    net.gradient_step(X[:BATCH], Y[:BATCH], STEP, MOMENTUM)  # warm
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds:
+        r = (steps % 4) * BATCH
+        net.gradient_step(X[r:r + BATCH], Y[r:r + BATCH], STEP, MOMENTUM)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(steps * BATCH / dt, 1), "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": "%d gradientSteps of batch %d on 784-300-100-10 (fp64, per-sample loop order of "
+                      "SCE:297-346; C restatement, not a JVM run)" % (steps, BATCH)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import gnn_amd
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    K, W = args.steps, args.warmup
+    n_batches = 64
+    X, Y = synthetic(BATCH * n_batches, 1000 + rank)  # each rank owns its row shard of the global batch
+    net = gnn_amd.SoftmaxCrossEntropyNeuralNet(DIMS, device=local_rank, max_batch=BATCH)
+    net.upload_dataset(X, Y)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        net.synchronize()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        def run(first_batch, n):
+            net.train_range((first_batch % n_batches) * BATCH, BATCH, n, STEP, MOMENTUM)
+    else:
+        # data parallel: all kernels on torch's current stream, gradient buffer owned by torch so
+        # that RCCL reduces it in place
+        stream = torch.cuda.current_stream()
+        net.set_stream(stream.cuda_stream)
+        gbuf = torch.zeros(net.grad_elems, dtype=torch.float32, device="cuda")
+        net.bind_grad_buffer(gbuf.data_ptr(), gbuf.numel())
+        Bg = BATCH * world
+
+        def run(first_batch, n):
+            for s in range(n):
+                net.compute_gradient_range(((first_batch + s) % n_batches) * BATCH, BATCH)
+                dist.all_reduce(gbuf, op=dist.ReduceOp.SUM)
+                net.apply_update(Bg, STEP, MOMENTUM)
+
+    run(0, W)
+    barrier()
+    t0 = time.perf_counter()
+    run(W, K)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- dominant-kernel roofline: HIP events on the kernel's own stream, over the same step loop
+    roofline = None
+    cpu = None
+    if rank == 0:
+        net.timing_enable(True)
+        nt = min(K, 1000)
+        run(W + K, nt)
+        net.synchronize()
+        fwd_us, fwd_n = net.timing_read(0)
+        grad_us, grad_n = net.timing_read(1)
+        net.timing_enable(False)
+        flop = 2.0 * BATCH * DIMS[0] * DIMS[1]  # 128 x 784 x 300 contraction, both kernels
+        # the first-layer weight-gradient GEMM (784x300, K = batch) and the first forward GEMM
+        # carry the same FLOPs; quote the slower one as the dominant kernel
+        name, us, cnt = (("grad_gemm0(784x300xB)", grad_us, grad_n) if grad_us >= fwd_us
+                         else ("fwd_gemm0(Bx784x300)", fwd_us, fwd_n))
+        ach = flop / (us * 1e-6) / 1e12 if us > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(us, 3), "launches": cnt,
+                    "other": {"fwd_gemm0_us": round(fwd_us, 3), "grad_gemm0_us": round(grad_us, 3)}}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+    if rank == 0:
+        total = K * BATCH * world
+        line = {
+            "metric": "training samples/sec, 784-300-100-10 MLP batch 128",
+            "value": round(total / dt, 1), "unit": "samples/s",
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "784-300-100-10 SoftmaxCrossEntropyNeuralNet gradientStep, fp32, "
+                                   "batch 128 per GPU (BASELINE configs[1])",
+                       "global_batch": BATCH * world, "parallelism": "dp%d" % world,
+                       "step": STEP, "momentum": MOMENTUM, "inner_activation": "leaky_relu"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

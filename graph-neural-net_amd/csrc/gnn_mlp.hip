@@ -1,0 +1,711 @@
+// gnn_mlp.hip -- C ABI (include/gnn_mlp.h) over the gfx950 kernels in kernels.h.
+// Host orchestration of one gradientStep (SCE:297-346): forward GEMM chain, fused output
+// layer, backward-data GEMM chain, weight-gradient GEMMs with the momentum update fused into
+// their epilogue (single GPU) or written to the flat gradient buffer (data parallel).
+#include "../../include/gnn_mlp.h"
+#include "java_random.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gnn;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(GNN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+struct TimerClass {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+};
+
+} // namespace
+
+struct gnn_mlp {
+    int device = 0;
+    int L = 0;                 // layerDims.length
+    std::vector<int> dims, ld; // logical / padded widths
+    std::vector<size_t> w_off; // offset of W_l in the flat padded buffers
+    int64_t n_params = 0;      // unpadded
+    int64_t n_pad = 0;         // padded flat length
+    int out_kind = 0, inner_act = 0, last_act = 0, loss = 0, dtype = 0;
+    int max_batch = 0, cap_rows = 0;
+    int time = 0;
+
+    float *W = nullptr, *V = nullptr, *G_own = nullptr, *G = nullptr;
+    std::vector<float *> act;   // act[l] = f(z_l), l = 0..L-2 ; act[0] = f(x)
+    std::vector<float *> delta; // delta[l] = dE/dz_l, l = 1..L-1
+    float *logits = nullptr, *prob = nullptr, *ybuf = nullptr, *lossv = nullptr;
+    int32_t *labels = nullptr, *idxbuf = nullptr;
+    double *stage_x = nullptr, *stage_y = nullptr, *stage_out = nullptr;
+
+    float *DX = nullptr, *DY = nullptr; // device-resident dataset (A_0 = f(x) and y)
+    int64_t dataset_n = 0;
+
+    hipStream_t stream = nullptr, own_stream = nullptr;
+
+    bool timing = false;
+    TimerClass timers[3];
+};
+
+namespace {
+
+int check_handle(const gnn_mlp *h) {
+    if (!h) return fail(GNN_ERR_BAD_ARG, "null handle");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return fail(GNN_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return GNN_OK;
+}
+
+int grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+// ---- timing ---------------------------------------------------------------------------
+struct ScopedTimer {
+    gnn_mlp *h; int cls; bool on = false; size_t slot = 0;
+    ScopedTimer(gnn_mlp *h_, int c) : h(h_), cls(c) {
+        if (!h->timing) return;
+        TimerClass &t = h->timers[cls];
+        if (t.used >= 8192) return;
+        if (t.used >= t.start.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            t.start.push_back(a); t.stop.push_back(b);
+        }
+        slot = t.used++;
+        on = true;
+        (void)hipEventRecord(t.start[slot], h->stream);
+    }
+    ~ScopedTimer() {
+        if (on) (void)hipEventRecord(h->timers[cls].stop[slot], h->stream);
+    }
+};
+
+// ---- GEMM dispatch ----------------------------------------------------------------------
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+void launch_gemm_t(const GemmParams &p, hipStream_t s) {
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>), grid, dim3(256), 0, s, p);
+}
+
+// tile edge: keep >= ~256 workgroups in flight where the problem allows it (256 CUs)
+int pick_tile(int M, int N) {
+    auto tiles = [&](int b) { return (int64_t)((M + b - 1) / b) * ((N + b - 1) / b); };
+    if (tiles(128) >= 256) return 128;
+    if (tiles(64) >= 256) return 64;
+    return 32;
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+void launch_gemm(const GemmParams &p, hipStream_t s) {
+    switch (pick_tile(p.M, p.N)) {
+    case 128: launch_gemm_t<128, 128, A_KC, B_KC, EPI>(p, s); break;
+    case 64: launch_gemm_t<64, 64, A_KC, B_KC, EPI>(p, s); break;
+    default: launch_gemm_t<32, 32, A_KC, B_KC, EPI>(p, s); break;
+    }
+}
+
+// ---- forward (SCE:164-198): a0 = f(x) rows, B live rows ------------------------------------
+// leaves act[1..L-2], logits; the output kernel is launched by the caller via run_output.
+void forward(gnn_mlp *h, const float *a0, int B) {
+    const int B_pad = pad_up(B);
+    const float *in = a0;
+    for (int l = 1; l < h->L; l++) {
+        GemmParams p{};
+        p.A = in; p.lda = h->ld[l - 1];
+        p.B = h->W + h->w_off[l - 1]; p.ldb = h->ld[l];
+        p.M = B_pad; p.N = h->ld[l]; p.K = h->ld[l - 1];
+        p.m_true = B; p.n_true = h->dims[l];
+        p.act = h->inner_act;
+        if (l < h->L - 1) {
+            p.C = h->act[l]; p.ldc = h->ld[l];
+            if (l == 1) { ScopedTimer tm(h, GNN_K_FWD_GEMM0); launch_gemm<true, false, EPI_ACT>(p, h->stream); }
+            else launch_gemm<true, false, EPI_ACT>(p, h->stream);
+            in = h->act[l];
+        } else {
+            p.C = h->logits; p.ldc = h->ld[l];
+            if (l == 1) { ScopedTimer tm(h, GNN_K_FWD_GEMM0); launch_gemm<true, false, EPI_STORE>(p, h->stream); }
+            else launch_gemm<true, false, EPI_STORE>(p, h->stream);
+        }
+    }
+}
+
+void run_output(gnn_mlp *h, const float *y, int B, bool want_prob, bool want_delta, bool want_loss,
+                bool want_label) {
+    const int Lm = h->L - 1;
+    OutParams o{};
+    o.Z = h->logits; o.ldz = h->ld[Lm];
+    o.Y = y; o.ldy = h->ld[Lm];
+    o.prob = want_prob ? h->prob : nullptr; o.ldp = h->ld[Lm];
+    o.delta = want_delta ? h->delta[Lm] : nullptr; o.ldd = h->ld[Lm];
+    o.loss = want_loss ? h->lossv : nullptr;
+    o.label = want_label ? h->labels : nullptr;
+    o.B = B; o.B_pad = pad_up(B); o.n_true = h->dims[Lm]; o.n_pad = h->ld[Lm];
+    o.out_kind = h->out_kind; o.last_act = h->last_act;
+    hipLaunchKernelGGL(output_layer_kernel, dim3((o.B_pad + 3) / 4), dim3(256), 0, h->stream, o);
+}
+
+// ---- backward (SCE:229-287) + gradient / update -------------------------------------------
+// fused_update: G_l is consumed by the SGD epilogue and never written (single GPU);
+// otherwise G_l goes to the flat gradient buffer for the caller's all-reduce.
+void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_over_b, float momentum) {
+    const int B_pad = pad_up(B);
+    for (int l = h->L - 2; l >= 0; l--) {
+        if (l >= 1) { // delta_l = (delta_{l+1} . W_l^T) * f'(z_l)   -- before W_l is touched
+            GemmParams p{};
+            p.A = h->delta[l + 1]; p.lda = h->ld[l + 1];
+            p.B = h->W + h->w_off[l]; p.ldb = h->ld[l + 1];
+            p.C = h->delta[l]; p.ldc = h->ld[l];
+            p.M = B_pad; p.N = h->ld[l]; p.K = h->ld[l + 1];
+            p.m_true = B; p.n_true = h->dims[l];
+            p.aux = h->act[l]; p.ldaux = h->ld[l];
+            p.act = h->inner_act;
+            launch_gemm<true, true, EPI_DACT>(p, h->stream);
+        }
+        GemmParams g{}; // G_l = A_l^T . delta_{l+1}
+        g.A = (l == 0) ? a0 : h->act[l]; g.lda = h->ld[l];
+        g.B = h->delta[l + 1]; g.ldb = h->ld[l + 1];
+        g.ldc = h->ld[l + 1];
+        g.M = h->ld[l]; g.N = h->ld[l + 1]; g.K = B_pad;
+        g.m_true = h->dims[l]; g.n_true = h->dims[l + 1];
+        ScopedTimer *tm = (l == 0) ? new ScopedTimer(h, GNN_K_GRAD_GEMM0) : nullptr;
+        if (fused_update) {
+            g.C = nullptr;
+            g.W = h->W + h->w_off[l]; g.V = h->V + h->w_off[l];
+            g.step_over_b = step_over_b; g.momentum = momentum;
+            launch_gemm<false, false, EPI_SGD>(g, h->stream);
+        } else {
+            g.C = h->G + h->w_off[l];
+            launch_gemm<false, false, EPI_STORE>(g, h->stream);
+        }
+        delete tm;
+    }
+}
+
+int check_batch(const gnn_mlp *h, int B) {
+    if (B <= 0) return fail(GNN_ERR_BAD_ARG, "batch must be non-empty (reference: assert !batch.isEmpty(), SCE:300)");
+    if (B > h->max_batch) return fail(GNN_ERR_BAD_ARG, "B exceeds max_batch given to gnn_mlp_create");
+    return GNN_OK;
+}
+
+int check_range(const gnn_mlp *h, int64_t first, int B) {
+    if (!h->DX) return fail(GNN_ERR_STATE, "no dataset uploaded");
+    if (first < 0 || first + B > h->dataset_n) return fail(GNN_ERR_BAD_ARG, "dataset rows out of range");
+    return GNN_OK;
+}
+
+// host fp64 rows -> device staging -> padded f32 (A_0 = f(x) when apply_act)
+int stage_rows(gnn_mlp *h, const double *src, int d, int ld, int B, double *stage, float *dst, bool apply_act) {
+    HIP_TRY(hipMemcpyAsync(stage, src, sizeof(double) * (size_t)B * d, hipMemcpyHostToDevice, h->stream));
+    const int64_t rows_pad = pad_up(B);
+    hipLaunchKernelGGL(convert_rows_f64_kernel, dim3(grid_for(rows_pad * ld)), dim3(256), 0, h->stream, stage, d,
+                       dst, ld, (int64_t)B, rows_pad, h->inner_act, apply_act ? 1 : 0);
+    return GNN_OK;
+}
+
+int export_rows(gnn_mlp *h, const float *src, int ld, int d, int B, double *host_dst) {
+    hipLaunchKernelGGL(export_rows_f64_kernel, dim3(grid_for((int64_t)B * d)), dim3(256), 0, h->stream, src, ld, d,
+                       (int64_t)B, h->stage_out);
+    HIP_TRY(hipMemcpyAsync(host_dst, h->stage_out, sizeof(double) * (size_t)B * d, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return GNN_OK;
+}
+
+int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step, double momentum) {
+    ScopedTimer tm(h, GNN_K_STEP);
+    forward(h, a0, B);
+    run_output(h, y, B, false, true, false, false);
+    backward(h, a0, B, true, (float)(step / (double)B), (float)momentum);
+    h->time++;
+    HIP_TRY(hipGetLastError());
+    return GNN_OK;
+}
+
+// padded f32 flat <-> unpadded fp64 flat
+void pack_params(const gnn_mlp *h, const double *flat, std::vector<float> &out) {
+    out.assign((size_t)h->n_pad, 0.f);
+    size_t src = 0;
+    for (int l = 0; l < h->L - 1; l++) {
+        const int rows = h->dims[l], cols = h->dims[l + 1], ldc = h->ld[l + 1];
+        float *dst = out.data() + h->w_off[l];
+        for (int i = 0; i < rows; i++)
+            for (int j = 0; j < cols; j++) dst[(size_t)i * ldc + j] = (float)flat[src++];
+    }
+}
+void unpack_params(const gnn_mlp *h, const std::vector<float> &in, double *flat) {
+    size_t dst = 0;
+    for (int l = 0; l < h->L - 1; l++) {
+        const int rows = h->dims[l], cols = h->dims[l + 1], ldc = h->ld[l + 1];
+        const float *src = in.data() + h->w_off[l];
+        for (int i = 0; i < rows; i++)
+            for (int j = 0; j < cols; j++) flat[dst++] = (double)src[(size_t)i * ldc + j];
+    }
+}
+
+int get_flat(gnn_mlp *h, const float *dev, double *flat) {
+    if (!flat) return fail(GNN_ERR_BAD_ARG, "null output");
+    std::vector<float> tmp((size_t)h->n_pad);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), dev, sizeof(float) * (size_t)h->n_pad, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    unpack_params(h, tmp, flat);
+    return GNN_OK;
+}
+int set_flat(gnn_mlp *h, float *dev, const double *flat) {
+    if (!flat) return fail(GNN_ERR_BAD_ARG, "null input");
+    std::vector<float> tmp;
+    pack_params(h, flat, tmp);
+    HIP_TRY(hipMemcpyAsync(dev, tmp.data(), sizeof(float) * (size_t)h->n_pad, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return GNN_OK;
+}
+
+template <typename T> int dev_alloc(T **p, size_t n) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), sizeof(T) * (n ? n : 1)));
+    HIP_TRY(hipMemset(*p, 0, sizeof(T) * (n ? n : 1)));
+    return GNN_OK;
+}
+
+#define TRY(expr)                      \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != GNN_OK) return rc_; \
+    } while (0)
+
+} // namespace
+
+extern "C" {
+
+const char *gnn_mlp_last_error(void) { return g_last_error.c_str(); }
+
+int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act, int last_act, int loss,
+                   int64_t seed, int dtype, int device, int max_batch, gnn_mlp_t **out) {
+    if (!out) return fail(GNN_ERR_BAD_ARG, "out is null");
+    *out = nullptr;
+    if (!dims || n_dims < 2) return fail(GNN_ERR_BAD_ARG, "layerDims must hold at least 2 entries (SCE:105)");
+    for (int i = 0; i < n_dims; i++)
+        if (dims[i] <= 0) return fail(GNN_ERR_BAD_ARG, "layer dimensions must be positive (SCE:142)");
+    if (out_kind != GNN_OUT_SOFTMAX_CE && out_kind != GNN_OUT_ACT_LOSS) return fail(GNN_ERR_BAD_ARG, "bad out_kind");
+    if (inner_act < 0 || inner_act > GNN_ACT_IDENTITY) return fail(GNN_ERR_BAD_ARG, "bad inner_act");
+    if (out_kind == GNN_OUT_ACT_LOSS && (last_act < 0 || last_act > GNN_ACT_IDENTITY))
+        return fail(GNN_ERR_BAD_ARG, "bad last_act");
+    if (out_kind == GNN_OUT_ACT_LOSS && loss != GNN_LOSS_HALF_SQUARED) return fail(GNN_ERR_BAD_ARG, "bad loss");
+    if (dtype != GNN_DTYPE_F32) return fail(GNN_ERR_UNSUPPORTED, "only GNN_DTYPE_F32 is built in this round");
+    if (max_batch <= 0) return fail(GNN_ERR_BAD_ARG, "max_batch must be positive");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GNN_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(GNN_ERR_BAD_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    gnn_mlp *h = new gnn_mlp();
+    h->device = device;
+    h->L = n_dims;
+    h->dims.assign(dims, dims + n_dims);
+    h->ld.resize(n_dims);
+    for (int i = 0; i < n_dims; i++) h->ld[i] = pad_up(dims[i]);
+    h->out_kind = out_kind; h->inner_act = inner_act; h->last_act = last_act; h->loss = loss; h->dtype = dtype;
+    h->max_batch = max_batch;
+    h->cap_rows = pad_up(max_batch);
+    h->w_off.resize(n_dims - 1);
+    size_t off = 0;
+    for (int l = 0; l < n_dims - 1; l++) {
+        h->w_off[l] = off;
+        off += (size_t)h->ld[l] * h->ld[l + 1];
+        h->n_params += (int64_t)dims[l] * dims[l + 1];
+    }
+    h->n_pad = (int64_t)off;
+
+    auto cleanup = [&](int rc) { gnn_mlp_destroy(h); return rc; };
+#define CTRY(expr) do { int rc_ = (expr); if (rc_ != GNN_OK) return cleanup(rc_); } while (0)
+    {
+        hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return cleanup(fail(GNN_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)));
+        h->stream = h->own_stream;
+    }
+    CTRY(dev_alloc(&h->W, (size_t)h->n_pad));
+    CTRY(dev_alloc(&h->V, (size_t)h->n_pad));
+    CTRY(dev_alloc(&h->G_own, (size_t)h->n_pad));
+    h->G = h->G_own;
+    h->act.assign(n_dims, nullptr);
+    h->delta.assign(n_dims, nullptr);
+    const size_t rows = (size_t)h->cap_rows;
+    for (int l = 0; l < n_dims - 1; l++) CTRY(dev_alloc(&h->act[l], rows * h->ld[l]));
+    for (int l = 1; l < n_dims; l++) CTRY(dev_alloc(&h->delta[l], rows * h->ld[l]));
+    const int ldo = h->ld[n_dims - 1];
+    CTRY(dev_alloc(&h->logits, rows * ldo));
+    CTRY(dev_alloc(&h->prob, rows * ldo));
+    CTRY(dev_alloc(&h->ybuf, rows * ldo));
+    CTRY(dev_alloc(&h->lossv, rows));
+    CTRY(dev_alloc(&h->labels, rows));
+    CTRY(dev_alloc(&h->idxbuf, rows));
+    CTRY(dev_alloc(&h->stage_x, (size_t)max_batch * dims[0]));
+    CTRY(dev_alloc(&h->stage_y, (size_t)max_batch * dims[n_dims - 1]));
+    {
+        size_t so = (size_t)max_batch * dims[n_dims - 1];
+        if (so < (size_t)max_batch) so = (size_t)max_batch;
+        CTRY(dev_alloc(&h->stage_out, so));
+    }
+#undef CTRY
+
+    // appendLayer (SCE:139-156): Random(seed), layer by layer, row-major, nextDouble() - 0.5
+    {
+        JavaRandom rnd(seed);
+        std::vector<double> flat((size_t)h->n_params);
+        size_t k = 0;
+        for (int l = 1; l < n_dims; l++)
+            for (int i = 0; i < dims[l - 1]; i++)
+                for (int j = 0; j < dims[l]; j++) flat[k++] = rnd.next_double() - 0.5;
+        int rc = set_flat(h, h->W, flat.data());
+        if (rc != GNN_OK) return cleanup(rc);
+    }
+    *out = h;
+    return GNN_OK;
+}
+
+int gnn_mlp_destroy(gnn_mlp_t *h) {
+    if (!h) return GNN_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    fr(h->W); fr(h->V); fr(h->G_own);
+    for (float *p : h->act) fr(p);
+    for (float *p : h->delta) fr(p);
+    fr(h->logits); fr(h->prob); fr(h->ybuf); fr(h->lossv); fr(h->labels); fr(h->idxbuf);
+    fr(h->stage_x); fr(h->stage_y); fr(h->stage_out); fr(h->DX); fr(h->DY);
+    for (TimerClass &t : h->timers) {
+        for (hipEvent_t e : t.start) (void)hipEventDestroy(e);
+        for (hipEvent_t e : t.stop) (void)hipEventDestroy(e);
+    }
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return GNN_OK;
+}
+
+int gnn_mlp_input_dim(const gnn_mlp_t *h) { return h ? h->dims[0] : -1; }
+int gnn_mlp_output_dim(const gnn_mlp_t *h) { return h ? h->dims[h->L - 1] : -1; }
+int64_t gnn_mlp_num_params(const gnn_mlp_t *h) { return h ? h->n_params : -1; }
+int gnn_mlp_time(const gnn_mlp_t *h) { return h ? h->time : -1; }
+int64_t gnn_mlp_dataset_size(const gnn_mlp_t *h) { return h ? h->dataset_n : -1; }
+int64_t gnn_mlp_grad_elems(const gnn_mlp_t *h) { return h ? h->n_pad : -1; }
+
+int gnn_mlp_propagate(gnn_mlp_t *h, const double *X, int B, double *out) {
+    TRY(check_handle(h));
+    if (!X || !out) return fail(GNN_ERR_BAD_ARG, "null argument (reference: assert input != null, SCE:165)");
+    TRY(check_batch(h, B));
+    TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
+    forward(h, h->act[0], B);
+    run_output(h, nullptr, B, true, false, false, false);
+    HIP_TRY(hipGetLastError());
+    return export_rows(h, h->prob, h->ld[h->L - 1], h->dims[h->L - 1], B, out);
+}
+
+static int read_loss(gnn_mlp *h, int B, double *loss_per_sample) {
+    std::vector<float> tmp((size_t)B);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->lossv, sizeof(float) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < B; i++) loss_per_sample[i] = (double)tmp[i];
+    return GNN_OK;
+}
+static int read_labels(gnn_mlp *h, int B, int32_t *labels) {
+    HIP_TRY(hipMemcpyAsync(labels, h->labels, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return GNN_OK;
+}
+
+int gnn_mlp_loss(gnn_mlp_t *h, const double *X, const double *Y, int B, double *loss_per_sample) {
+    TRY(check_handle(h));
+    if (!X || !Y || !loss_per_sample) return fail(GNN_ERR_BAD_ARG, "null argument (SCE:209)");
+    TRY(check_batch(h, B));
+    const int Lm = h->L - 1;
+    TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
+    TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
+    forward(h, h->act[0], B);
+    run_output(h, h->ybuf, B, false, false, true, false);
+    HIP_TRY(hipGetLastError());
+    return read_loss(h, B, loss_per_sample);
+}
+
+int gnn_mlp_argmax(gnn_mlp_t *h, const double *X, int B, int32_t *labels) {
+    TRY(check_handle(h));
+    if (!X || !labels) return fail(GNN_ERR_BAD_ARG, "null argument");
+    TRY(check_batch(h, B));
+    TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
+    forward(h, h->act[0], B);
+    run_output(h, nullptr, B, false, false, false, true);
+    HIP_TRY(hipGetLastError());
+    return read_labels(h, B, labels);
+}
+
+int gnn_mlp_compute_gradient(gnn_mlp_t *h, const double *X, const double *Y, int B) {
+    TRY(check_handle(h));
+    if (!X || !Y) return fail(GNN_ERR_BAD_ARG, "null argument (SCE:231)");
+    TRY(check_batch(h, B));
+    const int Lm = h->L - 1;
+    TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
+    TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
+    forward(h, h->act[0], B);
+    run_output(h, h->ybuf, B, false, true, false, false);
+    backward(h, h->act[0], B, false, 0.f, 0.f);
+    HIP_TRY(hipGetLastError());
+    return GNN_OK;
+}
+
+int gnn_mlp_weight_gradient(gnn_mlp_t *h, const double *X, const double *Y, int B, double *flat_grad) {
+    if (!flat_grad) return fail(GNN_ERR_BAD_ARG, "null output");
+    TRY(gnn_mlp_compute_gradient(h, X, Y, B));
+    return get_flat(h, h->G, flat_grad);
+}
+
+int gnn_mlp_gradient_step(gnn_mlp_t *h, const double *X, const double *Y, int B, double step, double momentum,
+                          int noise) {
+    TRY(check_handle(h));
+    if (!X || !Y) return fail(GNN_ERR_BAD_ARG, "null argument (reference: assert batch != null, SCE:299)");
+    TRY(check_batch(h, B));
+    if (noise) return fail(GNN_ERR_UNSUPPORTED, "noise=true is NaN-producing in the reference (SCE:335 sqrt of a negative draw) and is not built on the GPU");
+    if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
+    const int Lm = h->L - 1;
+    TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
+    TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
+    // the staging buffers are reused by the next call: pageable hipMemcpyAsync has returned
+    // only once the host data was consumed, and the convert kernels are stream-ordered.
+    return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum);
+}
+
+int gnn_mlp_get_weights(gnn_mlp_t *h, double *flat) { TRY(check_handle(h)); return get_flat(h, h->W, flat); }
+int gnn_mlp_set_weights(gnn_mlp_t *h, const double *flat) { TRY(check_handle(h)); return set_flat(h, h->W, flat); }
+int gnn_mlp_get_momentum(gnn_mlp_t *h, double *flat) { TRY(check_handle(h)); return get_flat(h, h->V, flat); }
+int gnn_mlp_set_momentum(gnn_mlp_t *h, const double *flat) { TRY(check_handle(h)); return set_flat(h, h->V, flat); }
+
+// ---- dataset ------------------------------------------------------------------------------
+static int alloc_dataset(gnn_mlp *h, int64_t N) {
+    if (h->DX) { (void)hipFree(h->DX); h->DX = nullptr; }
+    if (h->DY) { (void)hipFree(h->DY); h->DY = nullptr; }
+    h->dataset_n = 0;
+    const size_t rows = (size_t)N + PAD; // PAD zero rows behind the last sample: a batch's padding rows read them
+    TRY(dev_alloc(&h->DX, rows * h->ld[0]));
+    TRY(dev_alloc(&h->DY, rows * h->ld[h->L - 1]));
+    return GNN_OK;
+}
+
+int gnn_mlp_upload_dataset(gnn_mlp_t *h, const double *X, const double *Y, int64_t N) {
+    TRY(check_handle(h));
+    if (!X || !Y || N <= 0) return fail(GNN_ERR_BAD_ARG, "bad dataset");
+    TRY(alloc_dataset(h, N));
+    const int d0 = h->dims[0], dl = h->dims[h->L - 1];
+    const int64_t chunk = 4096;
+    double *sx = nullptr, *sy = nullptr;
+    HIP_TRY(hipMalloc((void **)&sx, sizeof(double) * chunk * d0));
+    HIP_TRY(hipMalloc((void **)&sy, sizeof(double) * chunk * dl));
+    for (int64_t r0 = 0; r0 < N; r0 += chunk) {
+        const int64_t n = (N - r0 < chunk) ? N - r0 : chunk;
+        (void)hipMemcpyAsync(sx, X + r0 * d0, sizeof(double) * n * d0, hipMemcpyHostToDevice, h->stream);
+        (void)hipMemcpyAsync(sy, Y + r0 * dl, sizeof(double) * n * dl, hipMemcpyHostToDevice, h->stream);
+        hipLaunchKernelGGL(convert_rows_f64_kernel, dim3(grid_for(n * h->ld[0])), dim3(256), 0, h->stream, sx, d0,
+                           h->DX + (size_t)r0 * h->ld[0], h->ld[0], n, n, h->inner_act, 1);
+        hipLaunchKernelGGL(convert_rows_f64_kernel, dim3(grid_for(n * h->ld[h->L - 1])), dim3(256), 0, h->stream, sy,
+                           dl, h->DY + (size_t)r0 * h->ld[h->L - 1], h->ld[h->L - 1], n, n, 0, 0);
+        (void)hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(sx); (void)hipFree(sy);
+    HIP_TRY(hipGetLastError());
+    h->dataset_n = N;
+    return GNN_OK;
+}
+
+int gnn_mlp_upload_dataset_u8(gnn_mlp_t *h, const uint8_t *pixels, const uint8_t *labels, int64_t N) {
+    TRY(check_handle(h));
+    if (!pixels || !labels || N <= 0) return fail(GNN_ERR_BAD_ARG, "bad dataset");
+    TRY(alloc_dataset(h, N));
+    const int d0 = h->dims[0], dl = h->dims[h->L - 1];
+    uint8_t *sp = nullptr, *sl = nullptr;
+    HIP_TRY(hipMalloc((void **)&sp, (size_t)N * d0));
+    HIP_TRY(hipMalloc((void **)&sl, (size_t)N));
+    HIP_TRY(hipMemcpyAsync(sp, pixels, (size_t)N * d0, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(sl, labels, (size_t)N, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(encode_u8_kernel, dim3(grid_for(N * h->ld[0])), dim3(256), 0, h->stream, sp, d0, h->DX, h->ld[0],
+                       N, N, h->inner_act);
+    hipLaunchKernelGGL(onehot_u8_kernel, dim3(grid_for(N * h->ld[h->L - 1])), dim3(256), 0, h->stream, sl, dl, h->DY,
+                       h->ld[h->L - 1], N, N);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(sp); (void)hipFree(sl);
+    HIP_TRY(hipGetLastError());
+    h->dataset_n = N;
+    return GNN_OK;
+}
+
+static int check_step_args(gnn_mlp *h, int B, double step, int noise) {
+    TRY(check_batch(h, B));
+    if (noise) return fail(GNN_ERR_UNSUPPORTED, "noise=true is not built on the GPU (SCE:335)");
+    if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
+    return GNN_OK;
+}
+
+int gnn_mlp_gradient_step_range(gnn_mlp_t *h, int64_t first, int B, double step, double momentum, int noise) {
+    TRY(check_handle(h));
+    TRY(check_step_args(h, B, step, noise));
+    TRY(check_range(h, first, B));
+    return step_on_rows(h, h->DX + (size_t)first * h->ld[0], h->DY + (size_t)first * h->ld[h->L - 1], B, step,
+                        momentum);
+}
+
+int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double step, double momentum) {
+    TRY(check_handle(h));
+    TRY(check_step_args(h, B, step, 0));
+    if (!h->DX) return fail(GNN_ERR_STATE, "no dataset uploaded");
+    if (n_steps <= 0) return fail(GNN_ERR_BAD_ARG, "n_steps must be positive (NNT:62)");
+    const int64_t nb = h->dataset_n / B;
+    if (nb <= 0 || first < 0 || first % B != 0) return fail(GNN_ERR_BAD_ARG, "first must be a multiple of B inside the dataset");
+    for (int s = 0; s < n_steps; s++) {
+        const int64_t row0 = ((first / B + s) % nb) * B;
+        TRY(step_on_rows(h, h->DX + (size_t)row0 * h->ld[0], h->DY + (size_t)row0 * h->ld[h->L - 1], B, step,
+                         momentum));
+    }
+    return GNN_OK;
+}
+
+static int gather_batch(gnn_mlp *h, const int32_t *idx, int B) {
+    for (int i = 0; i < B; i++)
+        if (idx[i] < 0 || idx[i] >= h->dataset_n) return fail(GNN_ERR_BAD_ARG, "sample index out of range");
+    HIP_TRY(hipMemcpyAsync(h->idxbuf, idx, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    const int B_pad = pad_up(B), Lm = h->L - 1;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * h->ld[0] / 4)), dim3(256), 0, h->stream,
+                       h->DX, h->ld[0], h->idxbuf, B, B_pad, h->act[0]);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * h->ld[Lm] / 4)), dim3(256), 0, h->stream,
+                       h->DY, h->ld[Lm], h->idxbuf, B, B_pad, h->ybuf);
+    return GNN_OK;
+}
+
+int gnn_mlp_gradient_step_indexed(gnn_mlp_t *h, const int32_t *idx, int B, double step, double momentum, int noise) {
+    TRY(check_handle(h));
+    if (!idx) return fail(GNN_ERR_BAD_ARG, "null index list");
+    TRY(check_step_args(h, B, step, noise));
+    if (!h->DX) return fail(GNN_ERR_STATE, "no dataset uploaded");
+    TRY(gather_batch(h, idx, B));
+    return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum);
+}
+
+int gnn_mlp_loss_range(gnn_mlp_t *h, int64_t first, int B, double *loss_per_sample) {
+    TRY(check_handle(h));
+    if (!loss_per_sample) return fail(GNN_ERR_BAD_ARG, "null output");
+    TRY(check_batch(h, B));
+    TRY(check_range(h, first, B));
+    forward(h, h->DX + (size_t)first * h->ld[0], B);
+    run_output(h, h->DY + (size_t)first * h->ld[h->L - 1], B, false, false, true, false);
+    HIP_TRY(hipGetLastError());
+    return read_loss(h, B, loss_per_sample);
+}
+
+int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels) {
+    TRY(check_handle(h));
+    if (!labels) return fail(GNN_ERR_BAD_ARG, "null output");
+    TRY(check_batch(h, B));
+    TRY(check_range(h, first, B));
+    forward(h, h->DX + (size_t)first * h->ld[0], B);
+    run_output(h, nullptr, B, false, false, false, true);
+    HIP_TRY(hipGetLastError());
+    return read_labels(h, B, labels);
+}
+
+// ---- data-parallel hooks --------------------------------------------------------------------
+int gnn_mlp_grad_device_ptr(gnn_mlp_t *h, void **dev_ptr) {
+    if (!h || !dev_ptr) return fail(GNN_ERR_BAD_ARG, "null argument");
+    *dev_ptr = h->G;
+    return GNN_OK;
+}
+
+int gnn_mlp_bind_grad_buffer(gnn_mlp_t *h, void *dev_ptr, int64_t n_elems) {
+    TRY(check_handle(h));
+    if (!dev_ptr) { h->G = h->G_own; return GNN_OK; }
+    if (n_elems < h->n_pad) return fail(GNN_ERR_BAD_ARG, "gradient buffer shorter than gnn_mlp_grad_elems()");
+    if (reinterpret_cast<uintptr_t>(dev_ptr) % 16) return fail(GNN_ERR_BAD_ARG, "gradient buffer must be 16-byte aligned");
+    h->G = static_cast<float *>(dev_ptr);
+    return GNN_OK;
+}
+
+int gnn_mlp_set_stream(gnn_mlp_t *h, void *hip_stream) {
+    TRY(check_handle(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return GNN_OK;
+}
+
+int gnn_mlp_compute_gradient_range(gnn_mlp_t *h, int64_t first, int B) {
+    TRY(check_handle(h));
+    TRY(check_batch(h, B));
+    TRY(check_range(h, first, B));
+    const float *a0 = h->DX + (size_t)first * h->ld[0];
+    forward(h, a0, B);
+    run_output(h, h->DY + (size_t)first * h->ld[h->L - 1], B, false, true, false, false);
+    backward(h, a0, B, false, 0.f, 0.f);
+    HIP_TRY(hipGetLastError());
+    return GNN_OK;
+}
+
+int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentum) {
+    TRY(check_handle(h));
+    if (B_global <= 0) return fail(GNN_ERR_BAD_ARG, "B_global must be positive");
+    if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
+    const int64_t n4 = h->n_pad / 4;
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(n4)), dim3(256), 0, h->stream,
+                       reinterpret_cast<float4 *>(h->W), reinterpret_cast<float4 *>(h->V),
+                       reinterpret_cast<const float4 *>(h->G), n4, (float)(step / (double)B_global), (float)momentum);
+    h->time++;
+    HIP_TRY(hipGetLastError());
+    return GNN_OK;
+}
+
+int gnn_mlp_synchronize(gnn_mlp_t *h) {
+    TRY(check_handle(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return GNN_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------
+int gnn_mlp_timing_enable(gnn_mlp_t *h, int on) {
+    TRY(check_handle(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->timing = on != 0;
+    for (TimerClass &t : h->timers) t.used = 0;
+    return GNN_OK;
+}
+
+int gnn_mlp_timing_read(gnn_mlp_t *h, int which, double *mean_us, int64_t *count) {
+    TRY(check_handle(h));
+    if (which < 0 || which > 2 || !mean_us || !count) return fail(GNN_ERR_BAD_ARG, "bad timing query");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    TimerClass &t = h->timers[which];
+    double total = 0.0;
+    for (size_t i = 0; i < t.used; i++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t.start[i], t.stop[i]));
+        total += ms;
+    }
+    *count = (int64_t)t.used;
+    *mean_us = t.used ? total * 1000.0 / (double)t.used : 0.0;
+    return GNN_OK;
+}
+
+} // extern "C"

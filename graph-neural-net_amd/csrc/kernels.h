@@ -1,0 +1,416 @@
+// kernels.h -- gfx950 (CDNA4, MI355X) device code of the MLP mini-batch SGD path.
+//
+// Every dense contraction of the reference's per-sample loop nests is a batched GEMM here:
+//   forward      Z_l  = A_{l-1} . W_{l-1}            (SCE:187-192)          "NN"
+//   backward     D_l  = (D_{l+1} . W_l^T) * f'(Z_l)  (SCE:272-278)          "NT"
+//   weight grad  G_l  = A_l^T . D_{l+1}              (SCE:253-258,279-283,
+//                                                     summed over the batch by SCE:305-322) "TN"
+// all on the exact-f32 matrix instruction v_mfma_f32_16x16x4_f32 (one k-ordered fmaf chain per
+// output element).  Operands are staged through LDS in a k-major image so that every MFMA
+// fragment read is a conflict-free ds_read_b32.
+//
+// Layout in HBM: every matrix is dense row-major f32 with its leading dimension rounded up to
+// PAD = 16 floats (64 B) and the padding kept at exactly 0, so no GEMM needs a remainder path:
+//   W_l   [ld(d_l)] rows x ld(d_{l+1}) cols  (the reference's weights[l][in][out], SCE:44-47)
+//   A_l   [B_pad]   rows x ld(d_l)           activations f(z_l), rows >= B are 0
+//   D_l   [B_pad]   rows x ld(d_l)           dE/dz_l
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gnn {
+
+constexpr int PAD = 16;
+__host__ __device__ constexpr int pad_up(int x, int m = PAD) { return (x + m - 1) / m * m; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum Act { ACT_LEAKY_RELU = 0, ACT_SIGMOID = 1, ACT_TANH = 2, ACT_RELU = 3, ACT_IDENTITY = 4 };
+
+// f(z): the reference's innerActivationFunc lambdas as a closed enum (MT:234).
+__device__ __forceinline__ float act_fn(int kind, float z) {
+    switch (kind) {
+    case ACT_LEAKY_RELU: return z > 0.f ? z : 0.01f * z;
+    case ACT_SIGMOID: return 1.f / (1.f + __expf(-z));
+    case ACT_TANH: return tanhf(z);
+    case ACT_RELU: return z > 0.f ? z : 0.f;
+    default: return z;
+    }
+}
+// f'(z) written in terms of a = f(z), which is what stays in HBM (MT:235: z<=0 -> 0.01;
+// a = f(z) has the sign of z and f(0) = 0, so `a > 0` decides the same branch).
+__device__ __forceinline__ float act_prime_from_a(int kind, float a) {
+    switch (kind) {
+    case ACT_LEAKY_RELU: return a > 0.f ? 1.f : 0.01f;
+    case ACT_SIGMOID: return a * (1.f - a);
+    case ACT_TANH: return 1.f - a * a;
+    case ACT_RELU: return a > 0.f ? 1.f : 0.f;
+    default: return 1.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GEMM  C[M x N] = opA(A)[M x K] . opB(B)[K x N]   with a fused epilogue.
+//   A_KC: A element (m,k) at A[m*lda + k]   (k contiguous)  else at A[k*lda + m]
+//   B_KC: B element (k,n) at B[n*ldb + k]   (k contiguous)  else at B[k*ldb + n]
+// M, N, K are the PADDED extents (multiples of 16); m_true / n_true are the logical extents:
+// outside them the epilogue stores exact zeros so the padding invariant survives every kernel.
+// ------------------------------------------------------------------------------------------
+enum Epi {
+    EPI_STORE = 0,       // C = acc                          (logits; gradients)
+    EPI_ACT = 1,         // C = f(acc)                       (hidden forward, SCE:184-186 of the next layer)
+    EPI_DACT = 2,        // C = acc * f'(aux)                (backward data, SCE:277)
+    EPI_SGD = 3          // v = step_over_b*acc + mu*V; W -= v; V = v   (SCE:333-339 fused into G_l)
+};
+
+struct GemmParams {
+    const float *A; int lda;
+    const float *B; int ldb;
+    float *C; int ldc;
+    int M, N, K;          // padded extents
+    int m_true, n_true;   // logical extents (zeros are stored beyond them)
+    const float *aux; int ldaux; // EPI_DACT: a = f(z) of this layer
+    float *W; float *V;   // EPI_SGD (same ld as C)
+    float step_over_b, momentum;
+    int act;
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    constexpr int BK = 32;
+    constexpr int TM = BM / 32, TN = BN / 32;   // 16x16 MFMA tiles per wave (waves are 2 x 2)
+    constexpr int LDAS = BM + 16, LDBS = BN + 16; // row stride = 16 (mod 32) floats: lanes 0-15 / 16-31 hit disjoint banks
+    __shared__ __attribute__((aligned(16))) float As[BK * LDAS];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDBS];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256; // float4 per thread per tile
+    static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+    float4 ra[NA], rb[NB];
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int idx = t + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (A_KC) {
+                const int m = idx % BM, kq = idx / BM;
+                if (m0 + m < p.M && k0 + kq * 4 < p.K)
+                    v = *reinterpret_cast<const float4 *>(p.A + (size_t)(m0 + m) * p.lda + k0 + kq * 4);
+            } else {
+                const int k = idx / (BM / 4), mq = idx % (BM / 4);
+                if (k0 + k < p.K && m0 + mq * 4 < p.M)
+                    v = *reinterpret_cast<const float4 *>(p.A + (size_t)(k0 + k) * p.lda + m0 + mq * 4);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int idx = t + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (B_KC) {
+                const int n = idx % BN, kq = idx / BN;
+                if (n0 + n < p.N && k0 + kq * 4 < p.K)
+                    v = *reinterpret_cast<const float4 *>(p.B + (size_t)(n0 + n) * p.ldb + k0 + kq * 4);
+            } else {
+                const int k = idx / (BN / 4), nq = idx % (BN / 4);
+                if (k0 + k < p.K && n0 + nq * 4 < p.N)
+                    v = *reinterpret_cast<const float4 *>(p.B + (size_t)(k0 + k) * p.ldb + n0 + nq * 4);
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int idx = t + i * 256;
+            if (A_KC) {
+                const int m = idx % BM, kq = idx / BM;
+                As[(kq * 4 + 0) * LDAS + m] = ra[i].x;
+                As[(kq * 4 + 1) * LDAS + m] = ra[i].y;
+                As[(kq * 4 + 2) * LDAS + m] = ra[i].z;
+                As[(kq * 4 + 3) * LDAS + m] = ra[i].w;
+            } else {
+                const int k = idx / (BM / 4), mq = idx % (BM / 4);
+                *reinterpret_cast<float4 *>(&As[k * LDAS + mq * 4]) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int idx = t + i * 256;
+            if (B_KC) {
+                const int n = idx % BN, kq = idx / BN;
+                Bs[(kq * 4 + 0) * LDBS + n] = rb[i].x;
+                Bs[(kq * 4 + 1) * LDBS + n] = rb[i].y;
+                Bs[(kq * 4 + 2) * LDBS + n] = rb[i].z;
+                Bs[(kq * 4 + 3) * LDBS + n] = rb[i].w;
+            } else {
+                const int k = idx / (BN / 4), nq = idx % (BN / 4);
+                *reinterpret_cast<float4 *>(&Bs[k * LDBS + nq * 4]) = rb[i];
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int a_base = fq * LDAS + wm * (TM * 16) + fr;
+    const int b_base = fq * LDBS + wn * (TN * 16) + fr;
+
+    load_tiles(0);
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        store_tiles();
+        __syncthreads();
+        if (k0 + BK < p.K) load_tiles(k0 + BK); // next tile's HBM/L2 latency hides under the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) a[i] = As[kk * LDAS + a_base + i * 16];
+#pragma unroll
+            for (int j = 0; j < TN; j++) b[j] = Bs[kk * LDBS + b_base + j * 16];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn * (TN * 16) + j * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + wm * (TM * 16) + i * 16 + fq * 4 + r;
+                if (m < p.M && n < p.N) {
+                    const bool live = (m < p.m_true) && (n < p.n_true);
+                    float v = acc[i][j][r];
+                    const size_t off = (size_t)m * p.ldc + n;
+                    if (EPI == EPI_STORE) {
+                        p.C[off] = live ? v : 0.f;
+                    } else if (EPI == EPI_ACT) {
+                        p.C[off] = live ? act_fn(p.act, v) : 0.f;
+                    } else if (EPI == EPI_DACT) {
+                        const float a = p.aux[(size_t)m * p.ldaux + n];
+                        p.C[off] = live ? v * act_prime_from_a(p.act, a) : 0.f;
+                    } else { // EPI_SGD: ((step*G)/B) + (momentum*prev), SCE:333
+                        if (live) {
+                            const float adj = p.step_over_b * v + p.momentum * p.V[off];
+                            p.W[off] -= adj;
+                            p.V[off] = adj;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Output layer, one wave per sample row.
+//   SOFTMAX_CE: p = softmax(z) (SCE:357-376; the row max IS subtracted here -- mathematically
+//   identical, and expf would overflow at the reference's |z| ~ 100 logits: SURVEY H2),
+//   delta = p - y (SCE:249-251), loss = -sum y ln p (SCE:213-217) evaluated in log space,
+//   label = argmax with `>=` (MT:166-168: ties -> highest index).
+//   ACT_LOSS  : a = f_last(z) (GNN:215-218), delta = loss'(a,y) * f_last'(z) (GNN:267-271),
+//   loss = sum loss(a,y) (GNN:236-239).
+// Rows >= B and columns >= n_true of `delta`/`prob` are written as zeros.
+// ------------------------------------------------------------------------------------------
+struct OutParams {
+    const float *Z; int ldz;    // logits [B_pad][ld]
+    const float *Y; int ldy;    // expected [rows][ld] (may be null when !want_delta && !want_loss)
+    float *prob; int ldp;       // may be null
+    float *delta; int ldd;      // may be null
+    float *loss;                // [B_pad] may be null
+    int32_t *label;             // [B_pad] may be null
+    int B, B_pad, n_true, n_pad;
+    int out_kind, last_act;
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.B_pad) return;
+    const bool live_row = row < p.B;
+    const float *z = p.Z + (size_t)row * p.ldz;
+    const float *y = p.Y ? p.Y + (size_t)row * p.ldy : nullptr;
+
+    if (p.out_kind == 0) {
+        float mx = -INFINITY;
+        int best = -1;
+        for (int c = lane; c < p.n_true; c += 64) {
+            const float v = z[c];
+            if (v >= mx) { mx = v; best = c; } // ascending c within a lane: `>=` keeps the highest
+        }
+        // wave argmax: larger value wins, equal values -> higher index (MT:166-168)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(mx, o);
+            const int ob = __shfl_xor(best, o);
+            if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
+        }
+        float s = 0.f;
+        for (int c = lane; c < p.n_true; c += 64) s += __expf(z[c] - mx);
+        s = wave_sum(s);
+        const float inv = 1.f / s;
+        const float lse = mx + __logf(s);
+        float l = 0.f;
+        for (int c = lane; c < p.n_pad; c += 64) {
+            const bool live = live_row && c < p.n_true;
+            const float pr = live ? __expf(z[c] - mx) * inv : 0.f;
+            const float yy = (live && y) ? y[c] : 0.f;
+            if (p.prob) p.prob[(size_t)row * p.ldp + c] = pr;
+            if (p.delta) p.delta[(size_t)row * p.ldd + c] = live ? pr - yy : 0.f;
+            if (live && yy != 0.f) l += yy * (lse - z[c]); // -y ln p
+        }
+        l = wave_sum(l);
+        if (lane == 0) {
+            if (p.loss) p.loss[row] = live_row ? l : 0.f;
+            if (p.label) p.label[row] = live_row ? best : -1;
+        }
+    } else {
+        float mx = -INFINITY;
+        int best = -1;
+        float l = 0.f;
+        for (int c = lane; c < p.n_pad; c += 64) {
+            const bool live = live_row && c < p.n_true;
+            const float zz = z[c];
+            const float a = act_fn(p.last_act, zz);
+            const float yy = (live && y) ? y[c] : 0.f;
+            const float d = a - yy; // loss' of 0.5*(a-y)^2
+            if (p.prob) p.prob[(size_t)row * p.ldp + c] = live ? a : 0.f;
+            if (p.delta) p.delta[(size_t)row * p.ldd + c] = live ? d * act_prime_from_a(p.last_act, a) : 0.f;
+            if (live) {
+                l += 0.5f * d * d;
+                if (a >= mx) { mx = a; best = c; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(mx, o);
+            const int ob = __shfl_xor(best, o);
+            if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
+        }
+        l = wave_sum(l);
+        if (lane == 0) {
+            if (p.loss) p.loss[row] = live_row ? l : 0.f;
+            if (p.label) p.label[row] = live_row ? best : -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Momentum update over the flat padded parameter buffer (SCE:327-342), 16 B per lane:
+//   adj = (step*G)/B + momentum*prev ; W -= adj ; prev = adj
+// Padding elements have G = 0 and prev = 0, so they stay exactly 0.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(float4 *__restrict__ W, float4 *__restrict__ V,
+                                                          const float4 *__restrict__ G, int64_t n4,
+                                                          float step_over_b, float momentum) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 g = G[i];
+        float4 v = V[i], w = W[i];
+        v.x = step_over_b * g.x + momentum * v.x;
+        v.y = step_over_b * g.y + momentum * v.y;
+        v.z = step_over_b * g.z + momentum * v.z;
+        v.w = step_over_b * g.w + momentum * v.w;
+        w.x -= v.x; w.y -= v.y; w.z -= v.z; w.w -= v.w;
+        V[i] = v;
+        W[i] = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Input encoding.  Host fp64 rows -> padded f32 rows; apply_act: the reference applies the
+// inner activation to the raw input too (SCE:183-186 with l-1 = 0), so A_0 = f(x).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void convert_rows_f64_kernel(const double *__restrict__ src, int d,
+                                                              float *__restrict__ dst, int ld, int64_t rows,
+                                                              int64_t rows_pad, int act, int apply_act) {
+    const int64_t total = rows_pad * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        float v = 0.f;
+        if (r < rows && c < d) {
+            v = (float)src[r * d + c];
+            if (apply_act) v = act_fn(act, v);
+        }
+        dst[i] = v;
+    }
+}
+
+// raw IDX bytes -> A_0 = f(pixel/255.0) (MT:98) and one-hot labels (MT:112-118)
+__global__ __launch_bounds__(256) void encode_u8_kernel(const uint8_t *__restrict__ pix, int d,
+                                                       float *__restrict__ dst, int ld, int64_t rows,
+                                                       int64_t rows_pad, int act) {
+    const int64_t total = rows_pad * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        float v = 0.f;
+        if (r < rows && c < d) v = act_fn(act, (float)((double)pix[r * d + c] / 255.0));
+        dst[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void onehot_u8_kernel(const uint8_t *__restrict__ lab, int n_classes,
+                                                       float *__restrict__ dst, int ld, int64_t rows,
+                                                       int64_t rows_pad) {
+    const int64_t total = rows_pad * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        dst[i] = (r < rows && c < n_classes && (int)lab[r] == c) ? 1.f : 0.f;
+    }
+}
+
+// gather dataset rows by index (one NNT.sample draw, NNT:143-158) into a dense batch
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int ld,
+                                                         const int32_t *__restrict__ idx, int B, int B_pad,
+                                                         float *__restrict__ dst) {
+    const int ld4 = ld / 4;
+    const int64_t total = (int64_t)B_pad * ld4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / ld4);
+        const int c = (int)(i - (int64_t)r * ld4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < B) v = reinterpret_cast<const float4 *>(src + (size_t)idx[r] * ld)[c];
+        reinterpret_cast<float4 *>(dst)[i] = v;
+    }
+}
+
+// f32 rows (padded) -> host-bound fp64 rows (unpadded)
+__global__ __launch_bounds__(256) void export_rows_f64_kernel(const float *__restrict__ src, int ld, int d,
+                                                             int64_t rows, double *__restrict__ dst) {
+    const int64_t total = rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / d;
+        const int c = (int)(i - r * d);
+        dst[i] = (double)src[r * ld + c];
+    }
+}
+
+} // namespace gnn

@@ -1,0 +1,183 @@
+/*
+ * gnn_mlp.h -- C ABI of the MI355X-native (gfx950) MLP mini-batch SGD path.
+ *
+ * This is the drop-in boundary for the hot path of asheptunov/graph-neural-net: the
+ * arithmetic of SoftmaxCrossEntropyNeuralNet / GeneralNeuralNet (the two implementations of
+ * the `NeuralNet` operator interface) moves behind these entry points; the Java NeuralNet /
+ * NeuralNetTrainer API surface above it stays.  The reference has no FFI of its own; the
+ * functions below are what a JNI shim for its `NeuralNet` interface binds (INTEGRATION.md shows
+ * the Java `native` declarations and the JNI stub for each).
+ *
+ * Citations are file:line under /root/reference/src.  NN = NeuralNet.java,
+ * SCE = SoftmaxCrossEntropyNeuralNet.java, GNN = GeneralNeuralNet.java,
+ * NNT = NeuralNetTrainer.java, MT = MNISTTrainer.java.
+ *
+ * Conventions
+ *  - plain C types only; every function returns a gnn_status (0 = ok) and never throws or
+ *    aborts across the ABI; gnn_mlp_last_error() gives the message of the calling thread's
+ *    last failure.
+ *  - host matrices are dense row-major fp64, exactly the reference's `double[]` rows laid end
+ *    to end: X is B x d_0, Y is B x d_{L-1}.  The reference passes one sample (or a
+ *    Map<double[],double[]>) per call; the shim flattens the Map in iteration order.
+ *  - flat parameter vectors (weights, momentum, gradients) are layer-major, each layer
+ *    row-major [in][out] like `weights.get(l)[in][out]` (SCE:44-47), UNPADDED, fp64 on the host.
+ *  - the library never keeps a host pointer past the call (the reference aliases the caller's
+ *    input array in neurons[0], SCE:167-168; no caller can observe that through NN:16-65).
+ *  - one handle = one GPU = one logical stream of calls; calls on one handle must be serialised
+ *    by the caller (the reference classes are not re-entrant either: `neurons` is shared scratch).
+ *  - there is NO CPU fallback: with no gfx950 device every entry point fails with
+ *    GNN_ERR_NO_DEVICE.
+ */
+#ifndef GNN_MLP_H
+#define GNN_MLP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gnn_mlp gnn_mlp_t;
+
+typedef enum {
+    GNN_OK = 0,
+    GNN_ERR_BAD_ARG = 1,     /* null pointer, bad dims, B out of range ... (reference: `assert`) */
+    GNN_ERR_HIP = 2,         /* a HIP runtime call failed; message holds hipGetErrorString */
+    GNN_ERR_UNSUPPORTED = 3, /* e.g. noise=1 (SCE:334-336 is NaN-producing) */
+    GNN_ERR_NO_DEVICE = 4,   /* no HIP device visible */
+    GNN_ERR_STATE = 5        /* e.g. indexed step before a dataset was uploaded */
+} gnn_status;
+
+/* Closed enum standing in for the reference's ActivationFunction / ActivationPrime lambdas
+ * (ActivationFunction.java:14, ActivationPrime.java:14).  LEAKY_RELU is the pair the
+ * reference ships: a>0 ? a : 0.01a  and  a<=0 ? 0.01 : 1.0  (MT:234-235). */
+typedef enum {
+    GNN_ACT_LEAKY_RELU = 0,
+    GNN_ACT_SIGMOID = 1,
+    GNN_ACT_TANH = 2,
+    GNN_ACT_RELU = 3,
+    GNN_ACT_IDENTITY = 4
+} gnn_act;
+
+typedef enum {
+    GNN_OUT_SOFTMAX_CE = 0, /* SoftmaxCrossEntropyNeuralNet: softmax + cross entropy (SCE:197,216,250) */
+    GNN_OUT_ACT_LOSS = 1    /* GeneralNeuralNet: last_act + loss (GNN:215-218,238,267-271) */
+} gnn_out_kind;
+
+typedef enum {
+    GNN_LOSS_HALF_SQUARED = 0 /* 0.5*(a-y)^2, derivative (a-y)  (LossFunction.java:16) */
+} gnn_loss;
+
+typedef enum {
+    GNN_DTYPE_F32 = 0, /* f32 operands, f32 MFMA (v_mfma_f32_16x16x4_f32), f32 accumulate */
+    GNN_DTYPE_BF16 = 1 /* bf16 GEMM operands, f32 accumulate, f32 master weights + momentum */
+} gnn_dtype;
+
+/* ---- construction (SCE:103-128 / GNN:112-147) ------------------------------------------- */
+
+/* Builds the net on HIP device `device` and draws the initial weights exactly as
+ * appendLayer does (SCE:139-156): java.util.Random(seed), layer by layer, row-major,
+ * nextDouble() - 0.5; momentum ("previousUpdate") zero; time 0.  The reference hard-codes
+ * seed 1 (SCE:111).  `last_act`/`loss` are ignored for GNN_OUT_SOFTMAX_CE.
+ * `max_batch` bounds B of every later call (device buffers are sized once, here). */
+int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act, int last_act,
+                   int loss, int64_t seed, int dtype, int device, int max_batch,
+                   gnn_mlp_t **out);
+int gnn_mlp_destroy(gnn_mlp_t *h);
+
+int gnn_mlp_input_dim(const gnn_mlp_t *h);    /* NN:58 getInputDim  (SCE:383) */
+int gnn_mlp_output_dim(const gnn_mlp_t *h);   /* NN:65 getOutputDim (SCE:392) */
+int64_t gnn_mlp_num_params(const gnn_mlp_t *h); /* sum_l d_l*d_{l+1} */
+int gnn_mlp_time(const gnn_mlp_t *h);         /* `time`: gradient steps taken (SCE:23,343) */
+const char *gnn_mlp_last_error(void);
+
+/* ---- the NeuralNet operator interface, batched ------------------------------------------ */
+
+/* NN:16 propagate (SCE:164-198, GNN:183-221) for B samples: out is B x d_{L-1}
+ * (softmax probabilities, or last_act(z) for GNN_OUT_ACT_LOSS).  Synchronous. */
+int gnn_mlp_propagate(gnn_mlp_t *h, const double *X, int B, double *out);
+
+/* NN:27 calculateLoss (SCE:207-220, GNN:230-242): loss_per_sample has B entries. */
+int gnn_mlp_loss(gnn_mlp_t *h, const double *X, const double *Y, int B, double *loss_per_sample);
+
+/* NN:39 calculateWeightGradient (SCE:229-287, GNN:251-307), summed over the B samples
+ * (B = 1 reproduces the reference call); flat_grad has gnn_mlp_num_params entries. */
+int gnn_mlp_weight_gradient(gnn_mlp_t *h, const double *X, const double *Y, int B,
+                            double *flat_grad);
+
+/* NN:51 gradientStep (SCE:297-346, GNN:317-366): G = sum over the batch of the per-sample
+ * gradients; adj = step*G/B + momentum*prev; W -= adj; prev = adj; time++.
+ * noise != 0 -> GNN_ERR_UNSUPPORTED.  Returns after enqueueing (asynchronous). */
+int gnn_mlp_gradient_step(gnn_mlp_t *h, const double *X, const double *Y, int B, double step,
+                          double momentum, int noise);
+
+/* MT:166-168 / MT:191-193 argmax of propagate(): `>=`, so ties go to the HIGHEST index. */
+int gnn_mlp_argmax(gnn_mlp_t *h, const double *X, int B, int32_t *labels);
+
+/* ---- parameter access (extension: `weights` is private with no getter, SCE:15) ----------- */
+int gnn_mlp_get_weights(gnn_mlp_t *h, double *flat);
+int gnn_mlp_set_weights(gnn_mlp_t *h, const double *flat);
+int gnn_mlp_get_momentum(gnn_mlp_t *h, double *flat);
+int gnn_mlp_set_momentum(gnn_mlp_t *h, const double *flat);
+
+/* ---- device-resident training data (the caller of the path: NNT:28-43, NNT:143-168) ------ */
+
+/* Copies N samples to HBM once (fp64 -> compute dtype, inner activation applied to the input
+ * as SCE:183-186 does for layer 0).  Later *_indexed / *_range calls do no host->device copy
+ * of sample data. */
+int gnn_mlp_upload_dataset(gnn_mlp_t *h, const double *X, const double *Y, int64_t N);
+/* Same from raw IDX payloads with the reference's encoding done on the GPU:
+ * pixel -> (byte & 0xff)/255.0 (MT:98), label -> one-hot 1.0 (MT:112-118). */
+int gnn_mlp_upload_dataset_u8(gnn_mlp_t *h, const uint8_t *pixels, const uint8_t *labels,
+                              int64_t N);
+int64_t gnn_mlp_dataset_size(const gnn_mlp_t *h);
+
+/* gradientStep on dataset rows idx[0..B) (host int32 indices, e.g. one NNT.sample draw). */
+int gnn_mlp_gradient_step_indexed(gnn_mlp_t *h, const int32_t *idx, int B, double step,
+                                  double momentum, int noise);
+/* gradientStep on the contiguous dataset rows [first, first+B). */
+int gnn_mlp_gradient_step_range(gnn_mlp_t *h, int64_t first, int B, double step,
+                                double momentum, int noise);
+/* n_steps consecutive gradientSteps (the loop NNT:82-85) over rows
+ * [first + s*B, first + (s+1)*B) mod the rows that fit, s = 0..n_steps-1, with no host work
+ * between steps. */
+int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double step,
+                        double momentum);
+int gnn_mlp_loss_range(gnn_mlp_t *h, int64_t first, int B, double *loss_per_sample);
+int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels);
+
+/* ---- data-parallel hooks (one process per GPU; the exchange is the caller's collective) -- */
+
+/* The reference sums per-sample gradients at SCE:305-322 and divides by batch.size() at
+ * SCE:333.  Sharded over ranks that sum becomes: each rank's partial G (its rows only) ->
+ * all-reduce(SUM) of the flat device gradient buffer -> identical update on every rank with
+ * B_global.  The buffer is fp32, gnn_mlp_grad_elems() long (padded layout, pads are zero). */
+int64_t gnn_mlp_grad_elems(const gnn_mlp_t *h);
+int gnn_mlp_grad_device_ptr(gnn_mlp_t *h, void **dev_ptr);
+/* Use a caller-owned device buffer (e.g. a torch tensor registered with RCCL) instead. */
+int gnn_mlp_bind_grad_buffer(gnn_mlp_t *h, void *dev_ptr, int64_t n_elems);
+/* Run all kernels on the caller's hipStream_t (e.g. torch's current stream); NULL = own. */
+int gnn_mlp_set_stream(gnn_mlp_t *h, void *hip_stream);
+/* forward + backward of dataset rows [first, first+B_local) into the gradient buffer. */
+int gnn_mlp_compute_gradient_range(gnn_mlp_t *h, int64_t first, int B_local);
+int gnn_mlp_compute_gradient(gnn_mlp_t *h, const double *X, const double *Y, int B_local);
+/* SCE:324-344 on the (all-reduced) gradient buffer with batchSize = B_global. */
+int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentum);
+int gnn_mlp_synchronize(gnn_mlp_t *h);
+
+/* ---- measurement support (bench.py) -------------------------------------------------------
+ * Mean duration in microseconds of the kernel class `which` over the launches since the last
+ * reset, measured with hipEvents on the handle's stream; timing must be enabled first
+ * (it serialises nothing but adds two event records per launch). */
+typedef enum {
+    GNN_K_FWD_GEMM0 = 0,  /* first forward GEMM  (B x d_0 x d_1) */
+    GNN_K_GRAD_GEMM0 = 1, /* first-layer weight-gradient GEMM (d_0 x d_1 x B) */
+    GNN_K_STEP = 2        /* one whole gradient step */
+} gnn_kernel_class;
+int gnn_mlp_timing_enable(gnn_mlp_t *h, int on);
+int gnn_mlp_timing_read(gnn_mlp_t *h, int which, double *mean_us, int64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNN_MLP_H */

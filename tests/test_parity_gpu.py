@@ -1,0 +1,308 @@
+"""GPU parity tests: the HIP path through the C ABI vs the fp64 CPU oracle on the same seeded
+inputs.  PARITY UNPINNED BY THE REFERENCE (it holds no tests or fixtures for this path and
+cannot run here); the oracle itself is pinned by tests/test_oracle.py.
+
+Tolerances (fp32 GEMMs on v_mfma_f32_16x16x4_f32 vs the fp64 serial loops):
+  * weights / momentum after a step: |dW| <= 2e-6 absolute (weights are O(0.5), one f32 ulp
+    there is 6e-8; the gradient is a K<=1024-term f32 sum),
+  * gradients: relative 2e-5 of the layer's max |G| (+ tiny absolute),
+  * softmax probabilities: 2e-4 absolute; loss: 2e-4 relative + 2e-4 absolute
+    (logits reach +-100 at the Random(1) init, so f32 logit error ~1e-5 relative dominates),
+  * argmax labels: bit-exact wherever the oracle's top-2 logit margin exceeds 1e-3;
+    the fixtures have no sample below that margin (asserted).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LEAKY, SIGMOID, TANH, RELU, IDENT = range(5)
+
+W_ATOL = 2e-6
+P_ATOL = 2e-4
+
+
+def make_batch(dims, B, seed=0, sparse=False):
+    rng = np.random.default_rng(seed)
+    X = rng.random((B, dims[0]))
+    if sparse:  # MNIST-like: ~19 % non-zeros
+        X *= rng.random((B, dims[0])) < 0.19
+    Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B)]
+    return X, Y
+
+
+def top2_margin(logits):
+    s = np.sort(logits, axis=1)
+    return s[:, -1] - s[:, -2]
+
+
+@pytest.mark.parametrize("dims,B", [([784, 100, 50, 10], 32), ([784, 300, 100, 10], 128),
+                                    ([5, 4, 3, 3], 1), ([20, 17, 33, 7], 19)])
+def test_init_matches_java_random(gnn, oracle_mod, dims, B):
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    ref = oracle_mod.OracleNet(dims)
+    w, wr = net.get_weights(), ref.get_weights()
+    # device weights are the fp32 rounding of the exact Random(1) draws
+    assert np.array_equal(w, wr.astype(np.float32).astype(np.float64))
+    assert np.all(net.get_momentum() == 0)
+    assert net.getInputDim() == dims[0] and net.getOutputDim() == dims[-1]
+    assert net.time == 0
+
+
+@pytest.mark.parametrize("dims,B,inner", [
+    ([784, 100, 50, 10], 32, LEAKY),
+    ([784, 300, 100, 10], 128, LEAKY),
+    ([784, 300, 100, 10], 128, SIGMOID),
+    ([5, 4, 3, 3], 1, LEAKY),
+    ([20, 17, 33, 7], 19, TANH),
+    ([64, 10], 7, RELU),
+])
+def test_sce_propagate_loss_argmax(gnn, oracle_mod, dims, B, inner):
+    X, Y = make_batch(dims, B, seed=1)
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    ref = oracle_mod.OracleNet(dims, inner_act=inner)
+    p, pr = net.propagate(X), ref.propagate(X)
+    assert p.shape == pr.shape
+    assert np.abs(p - pr).max() <= P_ATOL
+    assert np.abs(p.sum(axis=1) - 1).max() < 1e-5
+    l, lr = net.calculateLoss(X, Y), ref.calculate_loss(X, Y)
+    assert np.all(np.abs(l - lr) <= 2e-4 * np.abs(lr) + 2e-4)
+    margin = top2_margin(ref.logits(X))
+    assert (margin > 1e-3).all(), "fixture has a near-tie; pick another seed"
+    assert np.array_equal(net.argmax(X), ref.argmax(X))
+    # single-sample calls (the reference's own call shape, NN:16 / NN:27)
+    p1 = net.propagate(X[0])
+    assert p1.shape == (dims[-1],) and np.abs(p1 - pr[0]).max() <= P_ATOL
+    assert abs(net.calculateLoss(X[0], Y[0]) - lr[0]) <= 2e-4 * abs(lr[0]) + 2e-4
+
+
+@pytest.mark.parametrize("dims,B,inner", [
+    ([784, 100, 50, 10], 32, LEAKY),
+    ([784, 300, 100, 10], 128, LEAKY),
+    ([784, 300, 100, 10], 16, SIGMOID),
+    ([5, 4, 3, 3], 1, LEAKY),
+    ([20, 17, 33, 7], 19, TANH),
+    ([64, 10], 7, RELU),
+])
+def test_sce_weight_gradient(gnn, oracle_mod, dims, B, inner):
+    X, Y = make_batch(dims, B, seed=2)
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    ref = oracle_mod.OracleNet(dims, inner_act=inner)
+    g = net.calculateWeightGradient(X, Y)
+    gr = sum(ref.calculate_weight_gradient(X[b], Y[b]) for b in range(B))
+    off = 0
+    for l in range(len(dims) - 1):
+        n = dims[l] * dims[l + 1]
+        grl = gr[off:off + n].reshape(dims[l], dims[l + 1])
+        off += n
+        scale = np.abs(grl).max()
+        assert np.abs(g[l] - grl).max() <= 2e-5 * scale + 1e-9, "layer %d" % l
+
+
+@pytest.mark.parametrize("dims,B,inner,steps", [
+    ([784, 100, 50, 10], 32, LEAKY, 10),
+    ([784, 300, 100, 10], 128, LEAKY, 5),
+    ([784, 300, 100, 10], 128, SIGMOID, 3),
+    ([5, 4, 3, 3], 1, LEAKY, 20),
+    ([20, 17, 33, 7], 19, TANH, 10),
+    ([64, 10], 7, RELU, 10),
+])
+def test_sce_gradient_steps(gnn, oracle_mod, dims, B, inner, steps):
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    ref = oracle_mod.OracleNet(dims, inner_act=inner)
+    ref.set_alloc_per_sample(0)
+    for s in range(steps):
+        X, Y = make_batch(dims, B, seed=100 + s, sparse=(s % 2 == 1))
+        net.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+        ref.gradient_step(X, Y, 0.0125, 0.9)
+    assert net.time == steps == ref.time
+    dw = np.abs(net.get_weights() - ref.get_weights()).max()
+    dv = np.abs(net.get_momentum() - ref.get_momentum()).max()
+    assert dw <= W_ATOL * steps and dv <= W_ATOL * steps, (dw, dv)
+
+
+def test_gradient_step_map_form(gnn, oracle_mod):
+    """gradientStep(Map<double[],double[]>) call shape (NN:51): pairs in iteration order."""
+    dims = [12, 9, 4]
+    X, Y = make_batch(dims, 6, seed=3)
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=8)
+    ref = oracle_mod.OracleNet(dims)
+    net.gradientStep([(X[i], Y[i]) for i in range(6)], 0.05, 0.5, False)
+    ref.gradient_step(X, Y, 0.05, 0.5)
+    assert np.abs(net.get_weights() - ref.get_weights()).max() <= W_ATOL
+
+
+@pytest.mark.parametrize("inner,last", [(SIGMOID, SIGMOID), (LEAKY, SIGMOID), (TANH, IDENT), (SIGMOID, TANH)])
+def test_general_neural_net(gnn, oracle_mod, inner, last):
+    dims, B = [30, 21, 18, 5], 13
+    rng = np.random.default_rng(7)
+    X = rng.random((B, dims[0]))
+    Y = rng.random((B, dims[-1]))
+    net = gnn.GeneralNeuralNet(dims, inner_act=inner, last_act=last, max_batch=B)
+    ref = oracle_mod.OracleNet(dims, out_kind=oracle_mod.OUT_ACT_LOSS, inner_act=inner, last_act=last)
+    assert np.abs(net.propagate(X) - ref.propagate(X)).max() <= 2e-5
+    l, lr = net.calculateLoss(X, Y), ref.calculate_loss(X, Y)
+    assert np.all(np.abs(l - lr) <= 1e-4 * np.abs(lr) + 1e-5)
+    g = net.calculateWeightGradient(X[0], Y[0])
+    gr = ref.calculate_weight_gradient(X[0], Y[0])
+    off = 0
+    for l_ in range(len(dims) - 1):
+        n = dims[l_] * dims[l_ + 1]
+        grl = gr[off:off + n].reshape(dims[l_], dims[l_ + 1])
+        off += n
+        assert np.abs(g[l_] - grl).max() <= 5e-5 * np.abs(grl).max() + 1e-9
+    for s in range(5):
+        net.gradientStep(X, 0.1, 0.9, False, expected=Y)
+        ref.gradient_step(X, Y, 0.1, 0.9)
+    assert np.abs(net.get_weights() - ref.get_weights()).max() <= 5e-6
+
+
+def test_argmax_tie_rule(gnn):
+    """MT:166-168: `>=` so exact ties resolve to the HIGHEST index.  Zero weights make every
+    logit exactly 0 -> all classes tie -> label d_out-1."""
+    dims = [8, 6, 5]
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=4)
+    net.set_weights(np.zeros(net.n_params))
+    X = np.random.default_rng(0).random((4, 8))
+    assert np.array_equal(net.argmax(X), np.full(4, 4, dtype=np.int32))
+    p = net.propagate(X)
+    assert np.allclose(p, 0.2, atol=1e-7)
+    # two-way tie between classes 1 and 3 (identical weight columns), others lower
+    w = np.zeros((6, 5)); w[:, 1] = 1.0; w[:, 3] = 1.0
+    w0 = np.ones((8, 6))
+    net.set_weights(np.concatenate([w0.ravel(), w.ravel()]))
+    assert np.array_equal(net.argmax(X), np.full(4, 3, dtype=np.int32))
+
+
+def test_error_convention(gnn):
+    """Status codes instead of the reference's asserts; no aborts across the ABI."""
+    with pytest.raises(gnn.GnnError) as e:
+        gnn.SoftmaxCrossEntropyNeuralNet([5])
+    assert e.value.code == 1
+    with pytest.raises(gnn.GnnError):
+        gnn.SoftmaxCrossEntropyNeuralNet([5, 0, 3])
+    net = gnn.SoftmaxCrossEntropyNeuralNet([5, 4, 3], max_batch=4)
+    X, Y = make_batch([5, 4, 3], 4)
+    with pytest.raises(gnn.GnnError) as e:  # noise=true (SCE:334-336) is rejected, not silently different
+        net.gradientStep(X, 0.1, 0.9, True, expected=Y)
+    assert e.value.code == 3
+    with pytest.raises(gnn.GnnError):  # B > max_batch
+        net.propagate(np.zeros((5, 5)))
+    with pytest.raises(ValueError):
+        net.propagate(np.zeros((2, 6)))
+    with pytest.raises(gnn.GnnError) as e:
+        net.gradient_step_range(0, 2, 0.1, 0.9)
+    assert e.value.code == 5
+    with pytest.raises(gnn.GnnError):
+        net.gradientStep(X, -1.0, 0.9, False, expected=Y)
+
+
+def test_dataset_paths_agree(gnn, oracle_mod):
+    """host-batch, range and indexed steps are the same arithmetic; u8 upload == MT:98 encoding."""
+    dims, B, N = [784, 100, 50, 10], 32, 200
+    rng = np.random.default_rng(5)
+    pix = rng.integers(0, 256, (N, 784), dtype=np.uint8)
+    pix[rng.random((N, 784)) < 0.8] = 0
+    lab = rng.integers(0, 10, N, dtype=np.uint8)
+    X = pix.astype(np.float64) / 255.0           # MT:98
+    Y = np.eye(10)[lab]                          # MT:112-118
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    c = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    ref = oracle_mod.OracleNet(dims)
+    ref.set_alloc_per_sample(0)
+    b.upload_dataset(X, Y)
+    c.upload_dataset_u8(pix, lab)
+    assert b.dataset_size == N == c.dataset_size
+    for s in range(4):
+        rows = np.arange(s * B, (s + 1) * B)
+        a.gradientStep(X[rows], 0.0125, 0.9, False, expected=Y[rows])
+        b.gradient_step_range(s * B, B, 0.0125, 0.9)
+        c.gradient_step_indexed(rows, 0.0125, 0.9)
+        ref.gradient_step(X[rows], Y[rows], 0.0125, 0.9)
+    wa, wb, wc = a.get_weights(), b.get_weights(), c.get_weights()
+    assert np.array_equal(wa, wb) and np.array_equal(wa, wc)
+    assert np.abs(wa - ref.get_weights()).max() <= 4 * W_ATOL
+    # shuffled index draw, ragged batch (B not a multiple of 16), last rows of the dataset
+    idx = rng.permutation(N)[:27]
+    c.gradient_step_indexed(idx, 0.0125, 0.9)
+    ref.gradient_step(X[idx], Y[idx], 0.0125, 0.9)
+    b.gradient_step_range(N - 27, 27, 0.0125, 0.9)
+    assert np.abs(c.get_weights() - ref.get_weights()).max() <= 5 * W_ATOL
+    lr = ref.calculate_loss(X[N - 32:], Y[N - 32:])
+    lc = c.loss_range(N - 32, 32)
+    assert np.all(np.abs(lc - lr) <= 2e-4 * np.abs(lr) + 2e-4)
+    assert np.array_equal(c.argmax_range(N - 32, 32), ref.argmax(X[N - 32:]))
+
+
+def test_train_range_equals_stepwise(gnn):
+    dims, B, N = [64, 48, 10], 16, 96
+    X, Y = make_batch(dims, N, seed=9)
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    a.upload_dataset(X, Y); b.upload_dataset(X, Y)
+    a.train_range(32, B, 9, 0.05, 0.9)   # wraps around the 6 batches
+    for s in range(9):
+        b.gradient_step_range(((2 + s) % 6) * B, B, 0.05, 0.9)
+    assert a.time == 9
+    assert np.array_equal(a.get_weights(), b.get_weights())
+
+
+def test_data_parallel_hooks_single_rank(gnn, oracle_mod):
+    """compute_gradient_range + apply_update (the DP split of gradientStep) == the fused step;
+    two half-batches summed in the gradient buffer == one full batch."""
+    dims, B, N = [784, 300, 100, 10], 128, 256
+    X, Y = make_batch(dims, N, seed=11)
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    ref = oracle_mod.OracleNet(dims)
+    ref.set_alloc_per_sample(0)
+    a.upload_dataset(X, Y); b.upload_dataset(X, Y)
+    for s in range(2):
+        a.gradient_step_range(s * B, B, 0.0125, 0.9)
+        b.compute_gradient_range(s * B, B)
+        b.apply_update(B, 0.0125, 0.9)
+        ref.gradient_step(X[s * B:(s + 1) * B], Y[s * B:(s + 1) * B], 0.0125, 0.9)
+    assert b.time == 2
+    assert np.abs(a.get_weights() - b.get_weights()).max() <= 1e-7
+    assert np.abs(b.get_weights() - ref.get_weights()).max() <= 2 * W_ATOL
+
+
+@pytest.mark.parametrize("dims,B", [([4096, 2048, 2048, 1024], 512), ([784, 1024, 1024, 1024, 10], 256)])
+def test_full_size_configs_properties(gnn, dims, B):
+    """BASELINE configs 4 and 5 at full size, through size-independent properties (the serial
+    oracle would need minutes here): (1) gradient linearity -- G(batch) == G(first half) +
+    G(second half); (2) the fused-update step equals compute_gradient + apply_update;
+    (3) probabilities sum to 1; (4) a numpy fp64 matrix-form check of the logits on 4 rows."""
+    from tests import np_oracle
+    rng = np.random.default_rng(3)
+    X = rng.random((B, dims[0])) * (rng.random((B, dims[0])) < 0.19)
+    Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B)]
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    # scale the Random(1) weights down so that the softmax does not saturate at these widths
+    w = net.get_weights() * 0.05
+    net.set_weights(w)
+    w = net.get_weights()
+    p = net.propagate(X[:64])
+    assert np.abs(p.sum(axis=1) - 1).max() < 1e-5
+    Ws = np_oracle.split(w, dims)
+    _, pr = np_oracle.forward(Ws, X[:4], 0)
+    assert np.abs(p[:4] - pr).max() <= 5e-4
+    full = net.calculateWeightGradient(X, Y)
+    h1 = net.calculateWeightGradient(X[:B // 2], Y[:B // 2])
+    h2 = net.calculateWeightGradient(X[B // 2:], Y[B // 2:])
+    for l in full:
+        scale = np.abs(full[l]).max()
+        assert np.abs(full[l] - (h1[l] + h2[l])).max() <= 1e-5 * scale + 1e-9
+    gref = np_oracle.gradient(Ws, X[:8], Y[:8], 0)
+    g8 = net.calculateWeightGradient(X[:8], Y[:8])
+    g8f = np.concatenate([g8[l].ravel() for l in sorted(g8)])
+    assert np.abs(g8f - gref).max() <= 5e-5 * np.abs(gref).max()
+    net.upload_dataset(X, Y)
+    other = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    other.set_weights(w)
+    other.upload_dataset(X, Y)
+    net.gradient_step_range(0, B, 0.0125, 0.9)
+    other.compute_gradient_range(0, B)
+    other.apply_update(B, 0.0125, 0.9)
+    assert np.abs(net.get_weights() - other.get_weights()).max() <= 1e-7
