@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-path", action="store_true",
+                    help="run the data-parallel code path (compute -> all_reduce -> update) even at N=1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,9 +81,12 @@ def main():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.dp_path:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     K, W = args.steps, args.warmup
@@ -96,23 +101,18 @@ def main():
         net.synchronize()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if dist is None:
         def run(first_batch, n):
             net.train_range((first_batch % n_batches) * BATCH, BATCH, n, STEP, MOMENTUM)
     else:
-        # data parallel: all kernels on torch's current stream, gradient buffer owned by torch so
-        # that RCCL reduces it in place
-        stream = torch.cuda.current_stream()
-        net.set_stream(stream.cuda_stream)
-        gbuf = torch.zeros(net.grad_elems, dtype=torch.float32, device="cuda")
-        net.bind_grad_buffer(gbuf.data_ptr(), gbuf.numel())
-        Bg = BATCH * world
+        # data parallel (graph-neural-net_amd/data_parallel.py): kernels on torch's current stream,
+        # gradient buffer owned by torch so that RCCL reduces it in place, one all-reduce per step
+        from gnn_amd import data_parallel as dp
+        stepper = dp.DataParallelStep(dp.HipEngine(net, torch), dist)
 
         def run(first_batch, n):
             for s in range(n):
-                net.compute_gradient_range(((first_batch + s) % n_batches) * BATCH, BATCH)
-                dist.all_reduce(gbuf, op=dist.ReduceOp.SUM)
-                net.apply_update(Bg, STEP, MOMENTUM)
+                stepper.step(((first_batch + s) % n_batches) * BATCH, BATCH, STEP, MOMENTUM)
 
     run(0, W)
     barrier()
@@ -146,7 +146,7 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "avg_launch_us": round(us, 3), "launches": cnt,
                     "other": {"fwd_gemm0_us": round(fwd_us, 3), "grad_gemm0_us": round(grad_us, 3)}}
-        if world == 1 and not args.no_cpu_baseline:
+        if dist is None and not args.no_cpu_baseline:
             cpu = cpu_baseline()
 
     if dist is not None:

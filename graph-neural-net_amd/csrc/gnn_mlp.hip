@@ -281,9 +281,11 @@ int set_flat(gnn_mlp *h, float *dev, const double *flat) {
     return GNN_OK;
 }
 
-template <typename T> int dev_alloc(T **p, size_t n) {
+// Zero-filled device allocation.  The fill is enqueued on the HANDLE's stream: that stream is
+// non-blocking, so a legacy-stream hipMemset would not be ordered with the kernels that follow.
+template <typename T> int dev_alloc(T **p, size_t n, hipStream_t s) {
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), sizeof(T) * (n ? n : 1)));
-    HIP_TRY(hipMemset(*p, 0, sizeof(T) * (n ? n : 1)));
+    HIP_TRY(hipMemsetAsync(*p, 0, sizeof(T) * (n ? n : 1), s));
     return GNN_OK;
 }
 
@@ -345,28 +347,28 @@ int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act,
         if (e != hipSuccess) return cleanup(fail(GNN_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)));
         h->stream = h->own_stream;
     }
-    CTRY(dev_alloc(&h->W, (size_t)h->n_pad));
-    CTRY(dev_alloc(&h->V, (size_t)h->n_pad));
-    CTRY(dev_alloc(&h->G_own, (size_t)h->n_pad));
+    CTRY(dev_alloc(&h->W, (size_t)h->n_pad, h->stream));
+    CTRY(dev_alloc(&h->V, (size_t)h->n_pad, h->stream));
+    CTRY(dev_alloc(&h->G_own, (size_t)h->n_pad, h->stream));
     h->G = h->G_own;
     h->act.assign(n_dims, nullptr);
     h->delta.assign(n_dims, nullptr);
     const size_t rows = (size_t)h->cap_rows;
-    for (int l = 0; l < n_dims - 1; l++) CTRY(dev_alloc(&h->act[l], rows * h->ld[l]));
-    for (int l = 1; l < n_dims; l++) CTRY(dev_alloc(&h->delta[l], rows * h->ld[l]));
+    for (int l = 0; l < n_dims - 1; l++) CTRY(dev_alloc(&h->act[l], rows * h->ld[l], h->stream));
+    for (int l = 1; l < n_dims; l++) CTRY(dev_alloc(&h->delta[l], rows * h->ld[l], h->stream));
     const int ldo = h->ld[n_dims - 1];
-    CTRY(dev_alloc(&h->logits, rows * ldo));
-    CTRY(dev_alloc(&h->prob, rows * ldo));
-    CTRY(dev_alloc(&h->ybuf, rows * ldo));
-    CTRY(dev_alloc(&h->lossv, rows));
-    CTRY(dev_alloc(&h->labels, rows));
-    CTRY(dev_alloc(&h->idxbuf, rows));
-    CTRY(dev_alloc(&h->stage_x, (size_t)max_batch * dims[0]));
-    CTRY(dev_alloc(&h->stage_y, (size_t)max_batch * dims[n_dims - 1]));
+    CTRY(dev_alloc(&h->logits, rows * ldo, h->stream));
+    CTRY(dev_alloc(&h->prob, rows * ldo, h->stream));
+    CTRY(dev_alloc(&h->ybuf, rows * ldo, h->stream));
+    CTRY(dev_alloc(&h->lossv, rows, h->stream));
+    CTRY(dev_alloc(&h->labels, rows, h->stream));
+    CTRY(dev_alloc(&h->idxbuf, rows, h->stream));
+    CTRY(dev_alloc(&h->stage_x, (size_t)max_batch * dims[0], h->stream));
+    CTRY(dev_alloc(&h->stage_y, (size_t)max_batch * dims[n_dims - 1], h->stream));
     {
         size_t so = (size_t)max_batch * dims[n_dims - 1];
         if (so < (size_t)max_batch) so = (size_t)max_batch;
-        CTRY(dev_alloc(&h->stage_out, so));
+        CTRY(dev_alloc(&h->stage_out, so, h->stream));
     }
 #undef CTRY
 
@@ -501,12 +503,13 @@ int gnn_mlp_set_momentum(gnn_mlp_t *h, const double *flat) { TRY(check_handle(h)
 
 // ---- dataset ------------------------------------------------------------------------------
 static int alloc_dataset(gnn_mlp *h, int64_t N) {
+    HIP_TRY(hipStreamSynchronize(h->stream)); // nothing in flight may still read the old dataset
     if (h->DX) { (void)hipFree(h->DX); h->DX = nullptr; }
     if (h->DY) { (void)hipFree(h->DY); h->DY = nullptr; }
     h->dataset_n = 0;
     const size_t rows = (size_t)N + PAD; // PAD zero rows behind the last sample: a batch's padding rows read them
-    TRY(dev_alloc(&h->DX, rows * h->ld[0]));
-    TRY(dev_alloc(&h->DY, rows * h->ld[h->L - 1]));
+    TRY(dev_alloc(&h->DX, rows * h->ld[0], h->stream));
+    TRY(dev_alloc(&h->DY, rows * h->ld[h->L - 1], h->stream));
     return GNN_OK;
 }
 

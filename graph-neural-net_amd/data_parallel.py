@@ -1,0 +1,78 @@
+"""Data-parallel gradientStep: one process per GPU, one all-reduce per step.
+
+The reference sums the per-sample gradients of a batch serially (SCE:305-322) and divides by
+batch.size() in the update (SCE:333).  Samples are independent up to that sum, so the batch
+shards by rows: every rank holds the same weights and momentum, computes the partial sum G_r
+over its rows into ONE flat fp32 buffer (all layers contiguous), the ranks all-reduce(SUM) that
+buffer once (RCCL over xGMI through torch.distributed; gloo on CPU in the tests), and every
+rank applies the identical update with batchSize = the global batch.  No other collective is on
+the path.
+
+The engine behind `DataParallelStep` is anything with
+    grad_tensor                      flat torch tensor the all-reduce runs on, in place
+    compute_gradient_range(first, B) partial gradient of local dataset rows [first, first+B)
+    apply_update(B_global, step, momentum)
+`HipEngine` adapts a gnn_amd NeuralNet (the C ABI); tests drive the same class with a CPU
+engine over gloo.
+"""
+import numpy as np
+
+
+def shard_rows(n_rows, rank, world):
+    """Contiguous row block [lo, hi) of `rank`; the first n_rows % world ranks get one more."""
+    base, extra = divmod(int(n_rows), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class HipEngine:
+    """Binds a torch-owned CUDA tensor as the net's gradient buffer and moves the net's kernels
+    onto torch's current stream, so that compute -> all_reduce -> update are stream-ordered with
+    no host synchronisation."""
+
+    def __init__(self, net, torch_module):
+        torch = torch_module
+        self.net = net
+        self.grad_tensor = torch.zeros(net.grad_elems, dtype=torch.float32, device="cuda")
+        net.set_stream(torch.cuda.current_stream().cuda_stream)
+        net.bind_grad_buffer(self.grad_tensor.data_ptr(), self.grad_tensor.numel())
+
+    def compute_gradient_range(self, first, B):
+        self.net.compute_gradient_range(first, B)
+
+    def apply_update(self, B_global, step, momentum):
+        self.net.apply_update(B_global, step, momentum)
+
+    def weights_checksum(self):
+        w = self.net.get_weights()
+        return np.array([w.sum(), np.abs(w).sum()])
+
+
+class DataParallelStep:
+    def __init__(self, engine, dist_module=None, group=None):
+        self.engine = engine
+        self.dist = dist_module
+        self.group = group
+        self.world = dist_module.get_world_size(group) if dist_module is not None else 1
+        self.rank = dist_module.get_rank(group) if dist_module is not None else 0
+
+    def step(self, first, B_local, step, momentum):
+        """One global gradientStep; every rank passes its own local rows."""
+        self.engine.compute_gradient_range(first, B_local)
+        B_global = B_local
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(self.engine.grad_tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+            B_global = B_local * self.world
+        self.engine.apply_update(B_global, step, momentum)
+
+    def replicas_in_lockstep(self, torch_module, device="cpu"):
+        """True when every rank holds the same weights (the all-reduce result is bitwise identical
+        on all ranks, so replicas never drift)."""
+        if self.dist is None or self.world == 1:
+            return True
+        torch = torch_module
+        mine = torch.tensor(self.engine.weights_checksum(), dtype=torch.float64, device=device)
+        lo, hi = mine.clone(), mine.clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN, group=self.group)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.group)
+        return bool((lo == hi).all().item())

@@ -478,3 +478,28 @@ int oracle_sampler_sample(oracle_sampler *s, int batch, int32_t *out_idx) {
     }
     return n;
 }
+
+/* Deterministic synthetic inputs for fixtures: U[0,1) from the java.util.Random stream of
+ * `seed` (so the committed golden vectors need no bulk input data), optionally thinned to an
+ * MNIST-like density: a value is kept when a second draw is < keep (keep >= 1 keeps all). */
+void oracle_fill_uniform(int64_t seed, long n, double keep, double *out) {
+    jrandom r;
+    jrandom_seed(&r, seed);
+    for (long i = 0; i < n; i++) {
+        double v = jrandom_next_double(&r);
+        if (keep < 1.0) {
+            double u = jrandom_next_double(&r);
+            if (!(u < keep)) v = 0.0;
+        }
+        out[i] = v;
+    }
+}
+/* one-hot labels: label_i = nextInt(n_classes) of Random(seed) */
+void oracle_fill_onehot(int64_t seed, long rows, int n_classes, double *out) {
+    jrandom r;
+    jrandom_seed(&r, seed);
+    for (long i = 0; i < rows; i++) {
+        int c = jrandom_next_int_bound(&r, n_classes);
+        for (int j = 0; j < n_classes; j++) out[i * n_classes + j] = (j == c) ? 1.0 : 0.0;
+    }
+}

@@ -68,6 +68,8 @@ def lib():
     L.oracle_sampler_destroy.argtypes = [C.c_void_p]
     L.oracle_sampler_sample.restype = C.c_int
     L.oracle_sampler_sample.argtypes = [C.c_void_p, C.c_int, ip]
+    L.oracle_fill_uniform.argtypes = [C.c_int64, C.c_long, C.c_double, dp]
+    L.oracle_fill_onehot.argtypes = [C.c_int64, C.c_long, C.c_int, dp]
     # java.util.Random
     L.jrandom_seed.argtypes = [C.c_void_p, C.c_int64]
     L.jrandom_next_int.restype = C.c_int32
@@ -222,3 +224,13 @@ class Sampler:
             lib().oracle_sampler_destroy(self._h)
         except Exception:
             pass
+
+
+def synthetic_batch(dims, B, seed, keep=1.0):
+    """Deterministic (X, Y): X ~ U[0,1) from java.util.Random(seed) (thinned to density `keep`),
+    Y one-hot with label nextInt(d_out) of Random(seed + 1)."""
+    X = np.empty((B, dims[0]))
+    Y = np.empty((B, dims[-1]))
+    lib().oracle_fill_uniform(seed, X.size, keep, _dp(X))
+    lib().oracle_fill_onehot(seed + 1, B, dims[-1], _dp(Y))
+    return X, Y
