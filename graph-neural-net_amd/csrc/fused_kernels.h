@@ -1,0 +1,398 @@
+// fused_kernels.h -- the latency-oriented path for SMALL nets (the headline 784-300-100-10 at
+// batch 128 is 0.14 GFLOP per step: every kernel is bound by dependent-launch and memory
+// latency, not by MFMA or HBM throughput).  One gradientStep (SCE:297-346) is three launches:
+//
+//   fwd_first_kernel   A_1 = f(A_0 . W_0)            one 16x16 output tile per workgroup, the K
+//                                                     dimension split over the workgroup's waves
+//                                                     (in-LDS reduction, no global partials)
+//   middle_kernel      per 16-row block of the batch: forward through every remaining layer,
+//                      softmax / loss / delta_{L-1}, and the whole backward-data chain down to
+//                      delta_1 -- all per-sample independent (SCE:164-198, SCE:249-278), so a
+//                      workgroup needs no other workgroup's data
+//   grad_update_kernel every layer's G_l = A_l^T . delta_{l+1} (the only cross-sample sum,
+//                      SCE:305-322) with the momentum update (SCE:333-339) fused into the
+//                      epilogue, one launch for all layers
+//
+// All contractions run on v_mfma_f32_16x16x4_f32.  Operands that are k-contiguous in memory are
+// read 16 B per lane (4 consecutive k); the four k-slots of one MFMA then hold k = base+4q+j
+// (q = lane>>4) -- any assignment of distinct k to slots is valid as long as A and B agree.
+#pragma once
+#include "kernels.h"
+
+namespace gnn {
+
+constexpr int MAX_LAYERS = 8;
+
+// ------------------------------------------------------------------------------------------
+// fwd_first_kernel: C[M x N] = epi(A[M x K] . W[K x N]), A k-contiguous, W n-contiguous.
+// grid = (N/16, M/16); NW waves split K in 16-wide chunks.
+// ------------------------------------------------------------------------------------------
+struct FwdFirstParams {
+    const float *A; int lda;
+    const float *W; int ldw;
+    float *C; int ldc;
+    int M, N, K;          // padded extents (multiples of 16)
+    int m_true, n_true;
+    int act, apply_act;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void fwd_first_kernel(FwdFirstParams p) {
+    constexpr int MAXC = 8; // chunks whose loads are in flight at once (8 * (4+4) VGPRs)
+    __shared__ __attribute__((aligned(16))) float red[NW * 256];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int k16 = p.K / 16;
+    const int c_begin = (int)((long)wave * k16 / NW), c_end = (int)((long)(wave + 1) * k16 / NW);
+
+    const float *arow = p.A + (size_t)(m0 + fr) * p.lda + 4 * fq;
+    const float *wcol = p.W + (size_t)(4 * fq) * p.ldw + n0 + fr;
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int cb = c_begin; cb < c_end; cb += MAXC) {
+        float4 a[MAXC];
+        float b[MAXC][4];
+#pragma unroll
+        for (int i = 0; i < MAXC; i++) {
+            const int c = cb + i;
+            if (c < c_end) {
+                a[i] = *reinterpret_cast<const float4 *>(arow + c * 16);
+                const float *w = wcol + (size_t)(c * 16) * p.ldw;
+                b[i][0] = w[0];
+                b[i][1] = w[p.ldw];
+                b[i][2] = w[2 * p.ldw];
+                b[i][3] = w[3 * p.ldw];
+            } else {
+                a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                b[i][0] = b[i][1] = b[i][2] = b[i][3] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXC; i++) {
+            if (i & 1) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i][0], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i][1], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i][2], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i][3], acc1, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i][0], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i][1], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i][2], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i][3], acc0, 0, 0, 0);
+            }
+        }
+    }
+    f32x4 acc = acc0 + acc1;
+    *reinterpret_cast<f32x4 *>(&red[wave * 256 + lane * 4]) = acc;
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w * 256 + lane * 4]);
+        const int n = n0 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = m0 + fq * 4 + r;
+            const bool live = (m < p.m_true) && (n < p.n_true);
+            float v = s[r];
+            if (p.apply_act) v = act_fn(p.act, v);
+            p.C[(size_t)m * p.ldc + n] = live ? v : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// grad_update_kernel: G_l = A_l^T . D_{l+1} for every layer in one launch, K = batch rows.
+// One 32x32 tile of one layer per workgroup (4 waves, 2x2 MFMA tiles); the whole K extent is
+// staged to LDS in chunks of 128 rows.  FUSED: the momentum update replaces the store of G.
+// ------------------------------------------------------------------------------------------
+struct GradLayer {
+    const float *A; int lda;   // activations of layer l   [K][lda]
+    const float *D; int ldd;   // deltas of layer l+1      [K][ldd]
+    float *W; float *V; float *G; // all [M][ldd]
+    int M, N;                  // padded extents of W_l
+    int tiles_n, tile_begin;
+};
+struct GradParams {
+    GradLayer layer[MAX_LAYERS];
+    int n_layers;
+    int K;                     // padded batch rows
+    float step_over_b, momentum;
+};
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void grad_update_kernel(GradParams p) {
+    constexpr int KC = 128, LDS_LD = 48; // row stride = 16 (mod 32) floats
+    __shared__ __attribute__((aligned(16))) float As[KC * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Ds[KC * LDS_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fq = lane >> 4, wm = wave >> 1, wn = wave & 1;
+
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_LAYERS; i++)
+        if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].tile_begin) li = i;
+    const GradLayer &L = p.layer[li];
+    const int tile = blockIdx.x - L.tile_begin;
+    const int m0 = (tile / L.tiles_n) * 32, n0 = (tile % L.tiles_n) * 32;
+
+    const int m = m0 + wm * 16 + fq * 4; // + r
+    const int n = n0 + wn * 16 + fr;
+    const bool in_n = n < L.N;
+    // W / V of this lane's four outputs: issued first so that their latency hides under the GEMM
+    float w_old[4], v_old[4];
+    if (FUSED) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const bool ok = in_n && (m + r < L.M);
+            const size_t off = (size_t)(m + r) * L.ldd + n;
+            w_old[r] = ok ? L.W[off] : 0.f;
+            v_old[r] = ok ? L.V[off] : 0.f;
+        }
+    }
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += KC) {
+        const int kc = (p.K - k0 < KC) ? p.K - k0 : KC;
+        if (k0) __syncthreads();
+        // 32 floats (8 float4) per row per operand; thread -> (row = idx / 8, q = idx % 8)
+#pragma unroll
+        for (int i = 0; i < KC * 8 / 256; i++) {
+            const int idx = t + i * 256, k = idx >> 3, q = idx & 7;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vd = va;
+            if (k < kc) {
+                if (m0 + q * 4 < L.M) va = *reinterpret_cast<const float4 *>(L.A + (size_t)(k0 + k) * L.lda + m0 + q * 4);
+                if (n0 + q * 4 < L.N) vd = *reinterpret_cast<const float4 *>(L.D + (size_t)(k0 + k) * L.ldd + n0 + q * 4);
+            }
+            *reinterpret_cast<float4 *>(&As[k * LDS_LD + q * 4]) = va;
+            *reinterpret_cast<float4 *>(&Ds[k * LDS_LD + q * 4]) = vd;
+        }
+        __syncthreads();
+        const float *ap = &As[fq * LDS_LD + wm * 16 + fr];
+        const float *dp = &Ds[fq * LDS_LD + wn * 16 + fr];
+        for (int kk = 0; kk < kc; kk += 8) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * LDS_LD], dp[kk * LDS_LD], acc0, 0, 0, 0);
+            if (kk + 4 < kc)
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(kk + 4) * LDS_LD], dp[(kk + 4) * LDS_LD], acc1, 0, 0, 0);
+        }
+    }
+    const f32x4 acc = acc0 + acc1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (in_n && (m + r < L.M)) {
+            const size_t off = (size_t)(m + r) * L.ldd + n;
+            if (FUSED) { // ((step*G)/B) + (momentum*prev), SCE:333
+                const float adj = p.step_over_b * acc[r] + p.momentum * v_old[r];
+                L.W[off] = w_old[r] - adj;
+                L.V[off] = adj;
+            } else {
+                L.G[off] = acc[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// middle_kernel: everything between A_1 and delta_1 for one 16-row block of the batch.
+// ------------------------------------------------------------------------------------------
+struct MidParams {
+    int L;                       // layerDims.length
+    int d[MAX_LAYERS], ld[MAX_LAYERS];
+    const float *W[MAX_LAYERS];  // W[l]: weights between layers l and l+1, l = 1..L-2
+    float *act[MAX_LAYERS];      // act[1] (in), act[2..L-2] (out)
+    float *delta[MAX_LAYERS];    // delta[1..L-1] (out)
+    int kp_fwd[MAX_LAYERS];      // K-split of the GEMM producing layer l (l = 2..L-1)
+    int kp_bwd[MAX_LAYERS];      // K-split of the GEMM producing delta_l (l = 1..L-2)
+    int off_act[MAX_LAYERS];     // LDS float offsets: act images, l = 1..L-2
+    int off_logits, off_da, off_db, off_scratch;
+    const float *Y; int ldy;
+    float *prob; float *loss; int32_t *label;
+    int B;
+    int inner_act, out_kind, last_act;
+    int backward;                // 0: forward + output only
+};
+
+// C[16 x N] partials: scratch[kp][16][N] = A_lds[16 x Kpart] . B[Kpart x N]
+template <bool B_KC, int NW>
+__device__ __forceinline__ void wg_gemm16(const float *A_lds, int lda, int K, const float *__restrict__ Bg, int ldb,
+                                          int N, int KP, float *scratch, int wave, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int NT = N / 16, k16 = K / 16;
+    for (int item = wave; item < NT * KP; item += NW) {
+        const int nt = item % NT, kp = item / NT;
+        const int c_begin = kp * k16 / KP, c_end = (kp + 1) * k16 / KP;
+        const int n0 = nt * 16;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        constexpr int U = 4;
+        for (int cb = c_begin; cb < c_end; cb += U) {
+            f32x4 a[U], b[U];
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                const int k = (cb + i) * 16 + 4 * fq;
+                if (cb + i < c_end) {
+                    if (B_KC) {
+                        b[i] = *reinterpret_cast<const f32x4 *>(Bg + (size_t)(n0 + fr) * ldb + k);
+                    } else {
+                        const float *w = Bg + (size_t)k * ldb + n0 + fr;
+                        b[i] = (f32x4){w[0], w[ldb], w[2 * ldb], w[3 * ldb]};
+                    }
+                    a[i] = *reinterpret_cast<const f32x4 *>(A_lds + fr * lda + k);
+                } else {
+                    a[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    b[i] = a[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                if (i & 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], b[i][j], acc1, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], b[i][j], acc0, 0, 0, 0);
+                }
+            }
+        }
+        const f32x4 acc = acc0 + acc1;
+        float *dst = scratch + (size_t)kp * 16 * N + n0 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[(fq * 4 + r) * N] = acc[r];
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT_ = NW * 64;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row0 = blockIdx.x * 16;
+    const int Lm = p.L - 1;
+
+    // stage A_1 rows of this block (k-contiguous image, row stride ld+4)
+    {
+        const int ld1 = p.ld[1], lds1 = ld1 + 4, q4 = ld1 / 4;
+        float *dst = smem + p.off_act[1];
+        const float *src = p.act[1] + (size_t)row0 * ld1;
+        for (int e = t; e < 16 * q4; e += NT_) {
+            const int m = e / q4, q = e - m * q4;
+            *reinterpret_cast<float4 *>(dst + m * lds1 + q * 4) = *reinterpret_cast<const float4 *>(src + (size_t)m * ld1 + q * 4);
+        }
+    }
+    __syncthreads();
+
+    // forward: layers 2 .. L-1 (SCE:172-194)
+    for (int l = 2; l <= Lm; l++) {
+        const int K = p.ld[l - 1], N = p.ld[l], KP = p.kp_fwd[l];
+        wg_gemm16<false, NW>(smem + p.off_act[l - 1], K + 4, K, p.W[l - 1], N, N, KP, smem + p.off_scratch, wave, lane);
+        __syncthreads();
+        const bool last = (l == Lm);
+        float *dst = smem + (last ? p.off_logits : p.off_act[l]);
+        const int ldsn = N + 4;
+        for (int e = t; e < 16 * N; e += NT_) {
+            const int m = e / N, n = e - m * N;
+            float v = 0.f;
+            for (int kp = 0; kp < KP; kp++) v += smem[p.off_scratch + (kp * 16 + m) * N + n];
+            const bool live = (row0 + m < p.B) && (n < p.d[l]);
+            if (last) {
+                dst[m * ldsn + n] = live ? v : 0.f;
+            } else {
+                const float a = live ? act_fn(p.inner_act, v) : 0.f;
+                dst[m * ldsn + n] = a;
+                p.act[l][(size_t)(row0 + m) * N + n] = a;
+            }
+        }
+        __syncthreads();
+    }
+
+    // output layer: one wave per row (SCE:357-376, 249-251, 213-217 / GNN:215-218, 267-271; MT:166-168)
+    {
+        const int N = p.ld[Lm], nt = p.d[Lm], ldsn = N + 4;
+        float *da = smem + p.off_da;
+        for (int m = wave; m < 16; m += NW) {
+            const int row = row0 + m;
+            const bool live_row = row < p.B;
+            const float *z = smem + p.off_logits + m * ldsn;
+            const float *y = p.Y ? p.Y + (size_t)row * p.ldy : nullptr;
+            float mx = -INFINITY, l = 0.f;
+            int best = -1;
+            if (p.out_kind == 0) {
+                for (int c = lane; c < nt; c += 64) {
+                    const float v = z[c];
+                    if (v >= mx) { mx = v; best = c; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(mx, o);
+                    const int ob = __shfl_xor(best, o);
+                    if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
+                }
+                float s = 0.f;
+                for (int c = lane; c < nt; c += 64) s += __expf(z[c] - mx);
+                s = wave_sum(s);
+                const float inv = 1.f / s, lse = mx + __logf(s);
+                for (int c = lane; c < N; c += 64) {
+                    const bool live = live_row && c < nt;
+                    const float pr = live ? __expf(z[c] - mx) * inv : 0.f;
+                    const float yy = (live && y) ? y[c] : 0.f;
+                    if (p.prob) p.prob[(size_t)row * N + c] = pr;
+                    const float d = live ? pr - yy : 0.f;
+                    da[m * ldsn + c] = d;
+                    if (p.backward) p.delta[Lm][(size_t)row * N + c] = d;
+                    if (live && yy != 0.f) l += yy * (lse - z[c]);
+                }
+            } else {
+                for (int c = lane; c < N; c += 64) {
+                    const bool live = live_row && c < nt;
+                    const float a = act_fn(p.last_act, z[c]);
+                    const float yy = (live && y) ? y[c] : 0.f;
+                    const float df = a - yy;
+                    if (p.prob) p.prob[(size_t)row * N + c] = live ? a : 0.f;
+                    const float d = live ? df * act_prime_from_a(p.last_act, a) : 0.f;
+                    da[m * ldsn + c] = d;
+                    if (p.backward) p.delta[Lm][(size_t)row * N + c] = d;
+                    if (live) {
+                        l += 0.5f * df * df;
+                        if (a >= mx) { mx = a; best = c; }
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(mx, o);
+                    const int ob = __shfl_xor(best, o);
+                    if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
+                }
+            }
+            l = wave_sum(l);
+            if (lane == 0) {
+                if (p.loss) p.loss[row] = live_row ? l : 0.f;
+                if (p.label) p.label[row] = live_row ? best : -1;
+            }
+        }
+    }
+    if (!p.backward) return;
+    __syncthreads();
+
+    // backward data: delta_l = (delta_{l+1} . W_l^T) * f'(z_l), l = L-2 .. 1 (SCE:262-278)
+    int cur = p.off_da, nxt = p.off_db;
+    for (int l = Lm - 1; l >= 1; l--) {
+        const int K = p.ld[l + 1], N = p.ld[l], KP = p.kp_bwd[l];
+        wg_gemm16<true, NW>(smem + cur, K + 4, K, p.W[l], K, N, KP, smem + p.off_scratch, wave, lane);
+        __syncthreads();
+        const int ldsn = N + 4;
+        const float *aimg = smem + p.off_act[l];
+        for (int e = t; e < 16 * N; e += NT_) {
+            const int m = e / N, n = e - m * N;
+            float v = 0.f;
+            for (int kp = 0; kp < KP; kp++) v += smem[p.off_scratch + (kp * 16 + m) * N + n];
+            const bool live = (row0 + m < p.B) && (n < p.d[l]);
+            const float d = live ? v * act_prime_from_a(p.inner_act, aimg[m * ldsn + n]) : 0.f;
+            smem[nxt + m * ldsn + n] = d;
+            p.delta[l][(size_t)(row0 + m) * N + n] = d;
+        }
+        __syncthreads();
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+}
+
+} // namespace gnn

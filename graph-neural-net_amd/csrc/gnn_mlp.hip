@@ -4,12 +4,14 @@
 // their epilogue (single GPU) or written to the flat gradient buffer (data parallel).
 #include "../../include/gnn_mlp.h"
 #include "java_random.h"
+#include "fused_kernels.h"
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,6 +63,13 @@ struct gnn_mlp {
     int64_t dataset_n = 0;
 
     hipStream_t stream = nullptr, own_stream = nullptr;
+
+    // fused small-net path (fused_kernels.h): plan made once at create
+    bool fused = false;
+    MidParams mid{};
+    size_t mid_lds_bytes = 0;
+    GradParams grad{};
+    int grad_tiles = 0;
 
     bool timing = false;
     TimerClass timers[3];
@@ -204,6 +213,135 @@ void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_
     }
 }
 
+// ---- fused small-net path ---------------------------------------------------------------------
+constexpr int MID_NW = 16;   // waves per middle_kernel workgroup
+constexpr int FIRST_NW = 8;  // waves per fwd_first_kernel workgroup (K split in-LDS)
+
+int pick_kp(int NT, int k16, int N) {
+    int best = 1;
+    long best_cost = -1;
+    for (int kp = 1; kp <= k16 && kp <= 8; kp++) {
+        if ((long)kp * 16 * N * 4 > 48 * 1024) break;
+        const long cost = (long)((NT * kp + MID_NW - 1) / MID_NW) * ((k16 + kp - 1) / kp);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = kp; }
+    }
+    return best;
+}
+
+// Decides whether the net fits the fused path and lays out the middle kernel's LDS.
+void plan_fused(gnn_mlp *h) {
+    h->fused = false;
+    const char *env = getenv("GNN_MLP_PATH");
+    if (env && !strcmp(env, "generic")) return;
+    const int L = h->L, Lm = L - 1;
+    if (L < 3 || L > MAX_LAYERS) return;
+    long mid_w = 0;
+    for (int l = 1; l < Lm; l++) mid_w += (long)h->ld[l] * h->ld[l + 1];
+    if (mid_w > 160 * 1024) return; // every 16-row block streams all middle weights twice
+    MidParams &m = h->mid;
+    m = MidParams{};
+    m.L = L;
+    int off = 0, maxld = 0, scratch = 0;
+    for (int l = 0; l < L; l++) { m.d[l] = h->dims[l]; m.ld[l] = h->ld[l]; }
+    for (int l = 1; l < Lm; l++) { m.off_act[l] = off; off += 16 * (h->ld[l] + 4); }
+    m.off_logits = off; off += 16 * (h->ld[Lm] + 4);
+    for (int l = 1; l <= Lm; l++) maxld = h->ld[l] > maxld ? h->ld[l] : maxld;
+    m.off_da = off; off += 16 * (maxld + 4);
+    m.off_db = off; off += 16 * (maxld + 4);
+    for (int l = 2; l <= Lm; l++) {
+        m.kp_fwd[l] = pick_kp(h->ld[l] / 16, h->ld[l - 1] / 16, h->ld[l]);
+        const int s = m.kp_fwd[l] * 16 * h->ld[l];
+        scratch = s > scratch ? s : scratch;
+    }
+    for (int l = Lm - 1; l >= 1; l--) {
+        m.kp_bwd[l] = pick_kp(h->ld[l] / 16, h->ld[l + 1] / 16, h->ld[l]);
+        const int s = m.kp_bwd[l] * 16 * h->ld[l];
+        scratch = s > scratch ? s : scratch;
+    }
+    m.off_scratch = off; off += scratch;
+    const size_t bytes = (size_t)off * sizeof(float);
+    if (bytes > 150 * 1024) return;
+    h->mid_lds_bytes = bytes;
+    for (int l = 1; l < Lm; l++) m.W[l] = h->W + h->w_off[l];
+    for (int l = 1; l < Lm; l++) m.act[l] = h->act[l];
+    for (int l = 1; l <= Lm; l++) m.delta[l] = h->delta[l];
+    m.inner_act = h->inner_act; m.out_kind = h->out_kind; m.last_act = h->last_act;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&middle_kernel<MID_NW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    // gradient tiles: every layer's 32x32 tiles in one grid
+    GradParams &g = h->grad;
+    g = GradParams{};
+    g.n_layers = L - 1;
+    int tiles = 0;
+    for (int l = 0; l < L - 1; l++) {
+        GradLayer &gl = g.layer[l];
+        gl.A = h->act[l]; gl.lda = h->ld[l];
+        gl.D = h->delta[l + 1]; gl.ldd = h->ld[l + 1];
+        gl.W = h->W + h->w_off[l]; gl.V = h->V + h->w_off[l]; gl.G = h->G + h->w_off[l];
+        gl.M = h->ld[l]; gl.N = h->ld[l + 1];
+        gl.tiles_n = (gl.N + 31) / 32;
+        gl.tile_begin = tiles;
+        tiles += ((gl.M + 31) / 32) * gl.tiles_n;
+    }
+    h->grad_tiles = tiles;
+    h->fused = true;
+}
+
+// forward of the fused path; backward = also delta_1..delta_{L-1}
+void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
+                   bool want_loss, bool want_label) {
+    const int B_pad = pad_up(B);
+    FwdFirstParams f{};
+    f.A = a0; f.lda = h->ld[0];
+    f.W = h->W; f.ldw = h->ld[1];
+    f.C = h->act[1]; f.ldc = h->ld[1];
+    f.M = B_pad; f.N = h->ld[1]; f.K = h->ld[0];
+    f.m_true = B; f.n_true = h->dims[1];
+    f.act = h->inner_act; f.apply_act = 1;
+    {
+        ScopedTimer tm(h, GNN_K_FWD_GEMM0);
+        hipLaunchKernelGGL((fwd_first_kernel<FIRST_NW>), dim3(f.N / 16, f.M / 16), dim3(FIRST_NW * 64), 0, h->stream, f);
+    }
+    MidParams m = h->mid;
+    m.Y = y; m.ldy = h->ld[h->L - 1];
+    m.prob = want_prob ? h->prob : nullptr;
+    m.loss = want_loss ? h->lossv : nullptr;
+    m.label = want_label ? h->labels : nullptr;
+    m.B = B; m.backward = backward ? 1 : 0;
+    hipLaunchKernelGGL((middle_kernel<MID_NW>), dim3(B_pad / 16), dim3(MID_NW * 64), h->mid_lds_bytes, h->stream, m);
+}
+
+void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_over_b, float momentum) {
+    GradParams g = h->grad;
+    g.layer[0].A = a0;
+    for (int l = 0; l < g.n_layers; l++) g.layer[l].G = h->G + h->w_off[l];
+    g.K = pad_up(B);
+    g.step_over_b = step_over_b; g.momentum = momentum;
+    ScopedTimer tm(h, GNN_K_GRAD_GEMM0);
+    if (fused_update) hipLaunchKernelGGL((grad_update_kernel<true>), dim3(h->grad_tiles), dim3(256), 0, h->stream, g);
+    else hipLaunchKernelGGL((grad_update_kernel<false>), dim3(h->grad_tiles), dim3(256), 0, h->stream, g);
+}
+
+// the three shapes every entry point is made of
+void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_prob, bool want_loss, bool want_label) {
+    if (h->fused) { fused_forward(h, a0, y, B, false, want_prob, want_loss, want_label); return; }
+    forward(h, a0, B);
+    run_output(h, y, B, want_prob, false, want_loss, want_label);
+}
+void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum) {
+    if (h->fused) {
+        fused_forward(h, a0, y, B, true, false, false, false);
+        fused_gradient(h, a0, B, fused_update, step_over_b, momentum);
+        return;
+    }
+    forward(h, a0, B);
+    run_output(h, y, B, false, true, false, false);
+    backward(h, a0, B, fused_update, step_over_b, momentum);
+}
+
 int check_batch(const gnn_mlp *h, int B) {
     if (B <= 0) return fail(GNN_ERR_BAD_ARG, "batch must be non-empty (reference: assert !batch.isEmpty(), SCE:300)");
     if (B > h->max_batch) return fail(GNN_ERR_BAD_ARG, "B exceeds max_batch given to gnn_mlp_create");
@@ -235,9 +373,7 @@ int export_rows(gnn_mlp *h, const float *src, int ld, int d, int B, double *host
 
 int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step, double momentum) {
     ScopedTimer tm(h, GNN_K_STEP);
-    forward(h, a0, B);
-    run_output(h, y, B, false, true, false, false);
-    backward(h, a0, B, true, (float)(step / (double)B), (float)momentum);
+    do_gradient(h, a0, y, B, true, (float)(step / (double)B), (float)momentum);
     h->time++;
     HIP_TRY(hipGetLastError());
     return GNN_OK;
@@ -383,6 +519,7 @@ int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act,
         int rc = set_flat(h, h->W, flat.data());
         if (rc != GNN_OK) return cleanup(rc);
     }
+    plan_fused(h);
     *out = h;
     return GNN_OK;
 }
@@ -418,8 +555,7 @@ int gnn_mlp_propagate(gnn_mlp_t *h, const double *X, int B, double *out) {
     if (!X || !out) return fail(GNN_ERR_BAD_ARG, "null argument (reference: assert input != null, SCE:165)");
     TRY(check_batch(h, B));
     TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
-    forward(h, h->act[0], B);
-    run_output(h, nullptr, B, true, false, false, false);
+    do_forward(h, h->act[0], nullptr, B, true, false, false);
     HIP_TRY(hipGetLastError());
     return export_rows(h, h->prob, h->ld[h->L - 1], h->dims[h->L - 1], B, out);
 }
@@ -444,8 +580,7 @@ int gnn_mlp_loss(gnn_mlp_t *h, const double *X, const double *Y, int B, double *
     const int Lm = h->L - 1;
     TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
     TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
-    forward(h, h->act[0], B);
-    run_output(h, h->ybuf, B, false, false, true, false);
+    do_forward(h, h->act[0], h->ybuf, B, false, true, false);
     HIP_TRY(hipGetLastError());
     return read_loss(h, B, loss_per_sample);
 }
@@ -455,8 +590,7 @@ int gnn_mlp_argmax(gnn_mlp_t *h, const double *X, int B, int32_t *labels) {
     if (!X || !labels) return fail(GNN_ERR_BAD_ARG, "null argument");
     TRY(check_batch(h, B));
     TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
-    forward(h, h->act[0], B);
-    run_output(h, nullptr, B, false, false, false, true);
+    do_forward(h, h->act[0], nullptr, B, false, false, true);
     HIP_TRY(hipGetLastError());
     return read_labels(h, B, labels);
 }
@@ -468,9 +602,7 @@ int gnn_mlp_compute_gradient(gnn_mlp_t *h, const double *X, const double *Y, int
     const int Lm = h->L - 1;
     TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
     TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
-    forward(h, h->act[0], B);
-    run_output(h, h->ybuf, B, false, true, false, false);
-    backward(h, h->act[0], B, false, 0.f, 0.f);
+    do_gradient(h, h->act[0], h->ybuf, B, false, 0.f, 0.f);
     HIP_TRY(hipGetLastError());
     return GNN_OK;
 }
@@ -615,8 +747,7 @@ int gnn_mlp_loss_range(gnn_mlp_t *h, int64_t first, int B, double *loss_per_samp
     if (!loss_per_sample) return fail(GNN_ERR_BAD_ARG, "null output");
     TRY(check_batch(h, B));
     TRY(check_range(h, first, B));
-    forward(h, h->DX + (size_t)first * h->ld[0], B);
-    run_output(h, h->DY + (size_t)first * h->ld[h->L - 1], B, false, false, true, false);
+    do_forward(h, h->DX + (size_t)first * h->ld[0], h->DY + (size_t)first * h->ld[h->L - 1], B, false, true, false);
     HIP_TRY(hipGetLastError());
     return read_loss(h, B, loss_per_sample);
 }
@@ -626,8 +757,7 @@ int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels) {
     if (!labels) return fail(GNN_ERR_BAD_ARG, "null output");
     TRY(check_batch(h, B));
     TRY(check_range(h, first, B));
-    forward(h, h->DX + (size_t)first * h->ld[0], B);
-    run_output(h, nullptr, B, false, false, false, true);
+    do_forward(h, h->DX + (size_t)first * h->ld[0], nullptr, B, false, false, true);
     HIP_TRY(hipGetLastError());
     return read_labels(h, B, labels);
 }
@@ -660,9 +790,7 @@ int gnn_mlp_compute_gradient_range(gnn_mlp_t *h, int64_t first, int B) {
     TRY(check_batch(h, B));
     TRY(check_range(h, first, B));
     const float *a0 = h->DX + (size_t)first * h->ld[0];
-    forward(h, a0, B);
-    run_output(h, h->DY + (size_t)first * h->ld[h->L - 1], B, false, true, false, false);
-    backward(h, a0, B, false, 0.f, 0.f);
+    do_gradient(h, a0, h->DY + (size_t)first * h->ld[h->L - 1], B, false, 0.f, 0.f);
     HIP_TRY(hipGetLastError());
     return GNN_OK;
 }
