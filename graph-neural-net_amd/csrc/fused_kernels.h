@@ -24,8 +24,46 @@ namespace gnn {
 constexpr int MAX_LAYERS = 8;
 
 // ------------------------------------------------------------------------------------------
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (blocks b and b+8 share
+// an L2), and every kernel starts with a cold L2, so a tile's operand panels should be shared
+// with the OTHER tiles of the same XCD: the tile grid is cut into an xm x xn grid of rectangles
+// (xm*xn = 8), one rectangle per XCD label.  Placement is a speed matter only; a different
+// dispatch order changes nothing but L2 hit rates.
+// ------------------------------------------------------------------------------------------
+struct XcdTiling {
+    int tiles_m, tiles_n; // real tile counts
+    int xn;               // rectangles along n (xm = 8 / xn)
+    int rm, rn;           // rectangle extent in tiles
+    __host__ __device__ int blocks() const { return 8 * rm * rn; }
+    // local block id -> tile; false = idle block
+    __device__ __forceinline__ bool tile_of(int id, int &tm, int &tn) const {
+        const int x = id & 7, j = id >> 3;
+        tm = (x / xn) * rm + j / rn;
+        tn = (x % xn) * rn + j % rn;
+        return tm < tiles_m && tn < tiles_n && (j / rn) < rm;
+    }
+};
+inline XcdTiling make_xcd_tiling(int tiles_m, int tiles_n) {
+    XcdTiling best{};
+    long best_cost = -1;
+    for (int xn = 1; xn <= 8; xn *= 2) {
+        const int xm = 8 / xn;
+        const int rm = (tiles_m + xm - 1) / xm, rn = (tiles_n + xn - 1) / xn;
+        const long cost = (long)(rm + rn) * 1000 + (long)rm * rn; // panels fetched per XCD, then idle blocks
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = XcdTiling{tiles_m, tiles_n, xn, rm, rn}; }
+    }
+    return best;
+}
+
+#define GNN_STAMP_AT(ptr, i)                                                                  \
+    do {                                                                                      \
+        if (STAMP && threadIdx.x == 0) (ptr)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
 // fwd_first_kernel: C[M x N] = epi(A[M x K] . W[K x N]), A k-contiguous, W n-contiguous.
-// grid = (N/16, M/16); NW waves split K in 16-wide chunks.
+// One 16x16 output tile per workgroup; NW waves split K in 16-wide chunks, partial tiles are
+// summed through LDS.  Operands go straight to registers (no wave shares another's K slice).
 // ------------------------------------------------------------------------------------------
 struct FwdFirstParams {
     const float *A; int lda;
@@ -34,21 +72,27 @@ struct FwdFirstParams {
     int M, N, K;          // padded extents (multiples of 16)
     int m_true, n_true;
     int act, apply_act;
+    XcdTiling tiling;
+    unsigned long long *stamps; // STAMP builds only
 };
 
-template <int NW>
+template <int NW, bool STAMP = false, int ACT = -1>
 __global__ __launch_bounds__(NW * 64) void fwd_first_kernel(FwdFirstParams p) {
     constexpr int MAXC = 8; // chunks whose loads are in flight at once (8 * (4+4) VGPRs)
-    __shared__ __attribute__((aligned(16))) float red[NW * 256];
+    constexpr int RLD = 20; // row stride of a partial tile in LDS
+    __shared__ __attribute__((aligned(16))) float red[NW * 16 * RLD];
+    int tm, tn;
+    if (!p.tiling.tile_of(blockIdx.x, tm, tn)) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int n0 = tn * 16, m0 = tm * 16;
     const int k16 = p.K / 16;
     const int c_begin = (int)((long)wave * k16 / NW), c_end = (int)((long)(wave + 1) * k16 / NW);
 
     const float *arow = p.A + (size_t)(m0 + fr) * p.lda + 4 * fq;
     const float *wcol = p.W + (size_t)(4 * fq) * p.ldw + n0 + fr;
 
+    GNN_STAMP_AT(p.stamps, 0);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int cb = c_begin; cb < c_end; cb += MAXC) {
         float4 a[MAXC];
@@ -83,73 +127,85 @@ __global__ __launch_bounds__(NW * 64) void fwd_first_kernel(FwdFirstParams p) {
             }
         }
     }
-    f32x4 acc = acc0 + acc1;
-    *reinterpret_cast<f32x4 *>(&red[wave * 256 + lane * 4]) = acc;
+    const f32x4 acc = acc0 + acc1;
+    GNN_STAMP_AT(p.stamps, 1);
+    // partial tile, row-major: row = fq*4 + r, col = fr
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[(wave * 16 + fq * 4 + r) * RLD + fr] = acc[r];
     __syncthreads();
-    if (wave == 0) {
+    GNN_STAMP_AT(p.stamps, 2);
+    if (t < 64) { // thread -> (row m = t/4, 4 columns): one 16-B store per lane
+        const int m = t >> 2, q = t & 3;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w * 256 + lane * 4]);
-        const int n = n0 + fr;
+        for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[(w * 16 + m) * RLD + q * 4]);
+        float4 o;
+        float *ov = reinterpret_cast<float *>(&o);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int m = m0 + fq * 4 + r;
-            const bool live = (m < p.m_true) && (n < p.n_true);
-            float v = s[r];
-            if (p.apply_act) v = act_fn(p.act, v);
-            p.C[(size_t)m * p.ldc + n] = live ? v : 0.f;
+        for (int j = 0; j < 4; j++) {
+            const bool live = (m0 + m < p.m_true) && (n0 + q * 4 + j < p.n_true);
+            float v = s[j];
+            if (ACT >= 0) v = act_fn(ACT, v);
+            else if (p.apply_act) v = act_fn(p.act, v);
+            ov[j] = live ? v : 0.f;
         }
+        *reinterpret_cast<float4 *>(p.C + (size_t)(m0 + m) * p.ldc + n0 + q * 4) = o;
     }
+    GNN_STAMP_AT(p.stamps, 3);
 }
 
 // ------------------------------------------------------------------------------------------
 // grad_update_kernel: G_l = A_l^T . D_{l+1} for every layer in one launch, K = batch rows.
-// One 32x32 tile of one layer per workgroup (4 waves, 2x2 MFMA tiles); the whole K extent is
-// staged to LDS in chunks of 128 rows.  FUSED: the momentum update replaces the store of G.
+// One 32x32 tile of one layer per workgroup (4 waves, 2x2 MFMA tiles); the K extent is staged
+// to LDS in chunks of 128 rows.  FUSED: the momentum update replaces the store of G.
+// All global traffic is 16 B per lane: the accumulator tile is transposed through LDS so that
+// W, V (or G) move as whole 128-B rows.
 // ------------------------------------------------------------------------------------------
 struct GradLayer {
     const float *A; int lda;   // activations of layer l   [K][lda]
     const float *D; int ldd;   // deltas of layer l+1      [K][ldd]
     float *W; float *V; float *G; // all [M][ldd]
     int M, N;                  // padded extents of W_l
-    int tiles_n, tile_begin;
+    XcdTiling tiling;
+    int block_begin;           // first block of this layer (a multiple of 8)
 };
 struct GradParams {
     GradLayer layer[MAX_LAYERS];
     int n_layers;
     int K;                     // padded batch rows
     float step_over_b, momentum;
+    unsigned long long *stamps; // STAMP builds only
 };
 
-template <bool FUSED>
+template <bool FUSED, bool STAMP = false>
 __global__ __launch_bounds__(256) void grad_update_kernel(GradParams p) {
     constexpr int KC = 128, LDS_LD = 48; // row stride = 16 (mod 32) floats
+    constexpr int CLD = 36;
     __shared__ __attribute__((aligned(16))) float As[KC * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Ds[KC * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Cs[32 * CLD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, fq = lane >> 4, wm = wave >> 1, wn = wave & 1;
 
     int li = 0;
 #pragma unroll
     for (int i = 1; i < MAX_LAYERS; i++)
-        if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].tile_begin) li = i;
+        if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].block_begin) li = i;
     const GradLayer &L = p.layer[li];
-    const int tile = blockIdx.x - L.tile_begin;
-    const int m0 = (tile / L.tiles_n) * 32, n0 = (tile % L.tiles_n) * 32;
+    int tm, tn;
+    if (!L.tiling.tile_of(blockIdx.x - L.block_begin, tm, tn)) return;
+    const int m0 = tm * 32, n0 = tn * 32;
 
-    const int m = m0 + wm * 16 + fq * 4; // + r
-    const int n = n0 + wn * 16 + fr;
-    const bool in_n = n < L.N;
-    // W / V of this lane's four outputs: issued first so that their latency hides under the GEMM
-    float w_old[4], v_old[4];
-    if (FUSED) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const bool ok = in_n && (m + r < L.M);
-            const size_t off = (size_t)(m + r) * L.ldd + n;
-            w_old[r] = ok ? L.W[off] : 0.f;
-            v_old[r] = ok ? L.V[off] : 0.f;
-        }
+    // this thread's 16 B of the output tile: row er, columns 4*eq .. 4*eq+3
+    const int er = t >> 3, eq = t & 7;
+    const bool e_ok = (m0 + er < L.M) && (n0 + eq * 4 < L.N);
+    const size_t e_off = (size_t)(m0 + er) * L.ldd + n0 + eq * 4;
+    GNN_STAMP_AT(p.stamps, 0);
+    // W / V rows first: their latency hides under the GEMM
+    float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f), v_old = w_old;
+    if (FUSED && e_ok) {
+        w_old = *reinterpret_cast<const float4 *>(L.W + e_off);
+        v_old = *reinterpret_cast<const float4 *>(L.V + e_off);
     }
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -169,28 +225,44 @@ __global__ __launch_bounds__(256) void grad_update_kernel(GradParams p) {
             *reinterpret_cast<float4 *>(&Ds[k * LDS_LD + q * 4]) = vd;
         }
         __syncthreads();
+        GNN_STAMP_AT(p.stamps, 1);
         const float *ap = &As[fq * LDS_LD + wm * 16 + fr];
         const float *dp = &Ds[fq * LDS_LD + wn * 16 + fr];
-        for (int kk = 0; kk < kc; kk += 8) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * LDS_LD], dp[kk * LDS_LD], acc0, 0, 0, 0);
-            if (kk + 4 < kc)
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(kk + 4) * LDS_LD], dp[(kk + 4) * LDS_LD], acc1, 0, 0, 0);
+        // 16 k (4 MFMAs) per trip, operands of the whole trip read before the first MFMA
+        for (int kk = 0; kk < kc; kk += 16) {
+            float a[4], d[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                a[j] = ap[(kk + 4 * j) * LDS_LD];
+                d[j] = dp[(kk + 4 * j) * LDS_LD];
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], d[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], d[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], d[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], d[3], acc1, 0, 0, 0);
         }
     }
     const f32x4 acc = acc0 + acc1;
+    GNN_STAMP_AT(p.stamps, 2);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        if (in_n && (m + r < L.M)) {
-            const size_t off = (size_t)(m + r) * L.ldd + n;
-            if (FUSED) { // ((step*G)/B) + (momentum*prev), SCE:333
-                const float adj = p.step_over_b * acc[r] + p.momentum * v_old[r];
-                L.W[off] = w_old[r] - adj;
-                L.V[off] = adj;
-            } else {
-                L.G[off] = acc[r];
-            }
+    for (int r = 0; r < 4; r++) Cs[(wm * 16 + fq * 4 + r) * CLD + wn * 16 + fr] = acc[r];
+    __syncthreads();
+    if (e_ok) {
+        const float4 gsum = *reinterpret_cast<const float4 *>(&Cs[er * CLD + eq * 4]);
+        if (FUSED) { // ((step*G)/B) + (momentum*prev), SCE:333
+            float4 adj, wn_;
+            adj.x = p.step_over_b * gsum.x + p.momentum * v_old.x;
+            adj.y = p.step_over_b * gsum.y + p.momentum * v_old.y;
+            adj.z = p.step_over_b * gsum.z + p.momentum * v_old.z;
+            adj.w = p.step_over_b * gsum.w + p.momentum * v_old.w;
+            wn_.x = w_old.x - adj.x; wn_.y = w_old.y - adj.y; wn_.z = w_old.z - adj.z; wn_.w = w_old.w - adj.w;
+            *reinterpret_cast<float4 *>(L.W + e_off) = wn_;
+            *reinterpret_cast<float4 *>(L.V + e_off) = adj;
+        } else {
+            *reinterpret_cast<float4 *>(L.G + e_off) = gsum;
         }
     }
+    GNN_STAMP_AT(p.stamps, 3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -211,6 +283,7 @@ struct MidParams {
     int B;
     int inner_act, out_kind, last_act;
     int backward;                // 0: forward + output only
+    unsigned long long *stamps;  // diagnostic builds only (STAMP = true): [grid][16] s_memtime values
 };
 
 // C[16 x N] partials: scratch[kp][16][N] = A_lds[16 x Kpart] . B[Kpart x N]
@@ -261,13 +334,21 @@ __device__ __forceinline__ void wg_gemm16(const float *A_lds, int lda, int K, co
     }
 }
 
-template <int NW>
+// STAMP builds record s_memtime at every phase boundary into p.stamps (never into an output);
+// the shipped instantiation has STAMP = false and executes no stamp.
+#define GNN_STAMP(i)                                                                          \
+    do {                                                                                      \
+        if (STAMP && threadIdx.x == 0) p.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+template <int NW, bool STAMP = false>
 __global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT_ = NW * 64;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * 16;
     const int Lm = p.L - 1;
+    GNN_STAMP(0);
 
     // stage A_1 rows of this block (k-contiguous image, row stride ld+4)
     {
@@ -280,12 +361,14 @@ __global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
         }
     }
     __syncthreads();
+    GNN_STAMP(1);
 
     // forward: layers 2 .. L-1 (SCE:172-194)
     for (int l = 2; l <= Lm; l++) {
         const int K = p.ld[l - 1], N = p.ld[l], KP = p.kp_fwd[l];
         wg_gemm16<false, NW>(smem + p.off_act[l - 1], K + 4, K, p.W[l - 1], N, N, KP, smem + p.off_scratch, wave, lane);
         __syncthreads();
+        GNN_STAMP(2 * l - 2);
         const bool last = (l == Lm);
         float *dst = smem + (last ? p.off_logits : p.off_act[l]);
         const int ldsn = N + 4;
@@ -303,6 +386,7 @@ __global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
             }
         }
         __syncthreads();
+        GNN_STAMP(2 * l - 1);
     }
 
     // output layer: one wave per row (SCE:357-376, 249-251, 213-217 / GNN:215-218, 267-271; MT:166-168)
@@ -372,6 +456,7 @@ __global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
     }
     if (!p.backward) return;
     __syncthreads();
+    GNN_STAMP(2 * Lm);
 
     // backward data: delta_l = (delta_{l+1} . W_l^T) * f'(z_l), l = L-2 .. 1 (SCE:262-278)
     int cur = p.off_da, nxt = p.off_db;
@@ -379,6 +464,7 @@ __global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
         const int K = p.ld[l + 1], N = p.ld[l], KP = p.kp_bwd[l];
         wg_gemm16<true, NW>(smem + cur, K + 4, K, p.W[l], K, N, KP, smem + p.off_scratch, wave, lane);
         __syncthreads();
+        GNN_STAMP(2 * Lm + 1 + 2 * (Lm - 1 - l));
         const int ldsn = N + 4;
         const float *aimg = smem + p.off_act[l];
         for (int e = t; e < 16 * N; e += NT_) {
@@ -391,6 +477,7 @@ __global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
             p.delta[l][(size_t)(row0 + m) * N + n] = d;
         }
         __syncthreads();
+        GNN_STAMP(2 * Lm + 2 + 2 * (Lm - 1 - l));
         const int tmp = cur; cur = nxt; nxt = tmp;
     }
 }

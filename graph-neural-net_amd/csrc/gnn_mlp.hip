@@ -5,6 +5,7 @@
 #include "../../include/gnn_mlp.h"
 #include "java_random.h"
 #include "fused_kernels.h"
+#include "middle4_kernel.h"
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -70,6 +71,9 @@ struct gnn_mlp {
     size_t mid_lds_bytes = 0;
     GradParams grad{};
     int grad_tiles = 0;
+    bool mid4 = false;        // middle4_kernel (LDS-resident weights) instead of middle_kernel
+    Mid4Params mid4p{};
+    size_t mid4_lds_bytes = 0;
 
     bool timing = false;
     TimerClass timers[3];
@@ -228,6 +232,8 @@ int pick_kp(int NT, int k16, int N) {
     return best;
 }
 
+void plan_mid4(gnn_mlp *h);
+
 // Decides whether the net fits the fused path and lays out the middle kernel's LDS.
 void plan_fused(gnn_mlp *h) {
     h->fused = false;
@@ -282,12 +288,105 @@ void plan_fused(gnn_mlp *h) {
         gl.D = h->delta[l + 1]; gl.ldd = h->ld[l + 1];
         gl.W = h->W + h->w_off[l]; gl.V = h->V + h->w_off[l]; gl.G = h->G + h->w_off[l];
         gl.M = h->ld[l]; gl.N = h->ld[l + 1];
-        gl.tiles_n = (gl.N + 31) / 32;
-        gl.tile_begin = tiles;
-        tiles += ((gl.M + 31) / 32) * gl.tiles_n;
+        gl.tiling = make_xcd_tiling((gl.M + 31) / 32, (gl.N + 31) / 32);
+        gl.block_begin = tiles;
+        tiles += gl.tiling.blocks();
     }
     h->grad_tiles = tiles;
     h->fused = true;
+    plan_mid4(h);
+}
+
+// ---- middle4_kernel plan ----------------------------------------------------------------------
+template <int ACT, int OUTK, bool BWD> const void *mid4_fn() { return reinterpret_cast<const void *>(&middle4_kernel<ACT, OUTK, BWD>); }
+template <int ACT, int OUTK, bool BWD> void mid4_launch(const Mid4Params &p, int grid, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((middle4_kernel<ACT, OUTK, BWD>), dim3(grid), dim3(1024), lds, s, p);
+}
+#define MID4_DISPATCH(CALL)                                                                     \
+    switch (act * 4 + outk * 2 + (bwd ? 1 : 0)) {                                               \
+    case 0: CALL(0, 0, false); break; case 1: CALL(0, 0, true); break;                          \
+    case 2: CALL(0, 1, false); break; case 3: CALL(0, 1, true); break;                          \
+    case 4: CALL(1, 0, false); break; case 5: CALL(1, 0, true); break;                          \
+    case 6: CALL(1, 1, false); break; case 7: CALL(1, 1, true); break;                          \
+    case 8: CALL(2, 0, false); break; case 9: CALL(2, 0, true); break;                          \
+    case 10: CALL(2, 1, false); break; case 11: CALL(2, 1, true); break;                        \
+    case 12: CALL(3, 0, false); break; case 13: CALL(3, 0, true); break;                        \
+    case 14: CALL(3, 1, false); break; case 15: CALL(3, 1, true); break;                        \
+    case 16: CALL(4, 0, false); break; case 17: CALL(4, 0, true); break;                        \
+    case 18: CALL(4, 1, false); break; default: CALL(4, 1, true); break;                        \
+    }
+const void *mid4_function(int act, int outk, bool bwd) {
+    const void *f = nullptr;
+#define CALL(A, O, B) f = mid4_fn<A, O, B>()
+    MID4_DISPATCH(CALL)
+#undef CALL
+    return f;
+}
+void mid4_dispatch(int act, int outk, bool bwd, const Mid4Params &p, int grid, size_t lds, hipStream_t s) {
+#define CALL(A, O, B) mid4_launch<A, O, B>(p, grid, lds, s)
+    MID4_DISPATCH(CALL)
+#undef CALL
+}
+
+void plan_mid4(gnn_mlp *h) {
+    h->mid4 = false;
+    const char *env = getenv("GNN_MLP_PATH");
+    if (env && !strcmp(env, "fused16")) return;
+    const int L = h->L, Lm = L - 1;
+    Mid4Params &m = h->mid4p;
+    m = Mid4Params{};
+    m.L = L;
+    for (int l = 0; l < L; l++) { m.d[l] = h->dims[l]; m.ld[l] = h->ld[l]; m.kr[l] = (h->dims[l] + 3) / 4 * 4; }
+    int off = 0;
+    auto take = [&](int n) { const int o = off; off += (n + 3) / 4 * 4; return o; };
+    for (int l = 1; l < Lm; l++) m.off_w[l] = take(m.kr[l] * (h->ld[l + 1] + 1));
+    for (int l = 1; l < Lm; l++) m.off_act[l] = take(4 * (h->ld[l] + 4));
+    m.off_logits = take(4 * (h->ld[Lm] + 4));
+    for (int l = 2; l <= Lm; l++) m.off_dl[l] = take(4 * (h->ld[l] + 4));
+    m.off_y = take(4 * h->ld[Lm]);
+    m.off_scratch = off;
+    m.w_total4 = 0;
+    for (int l = 1; l < Lm; l++) {
+        const int c4 = h->ld[l + 1] / 4;
+        m.w_begin4[l] = m.w_total4;
+        m.w_total4 += m.kr[l] * c4;
+        m.w_inv_c4[l] = (unsigned)(((1ull << 32) + c4 - 1) / c4);
+    }
+    if (m.w_total4 >= (1 << 20)) return; // the reciprocal division is exact well beyond this
+    const int budget = (160 * 1024) / 4 - 128 - off; // floats left for the K-split partials
+    if (budget < 0) return;
+    int scratch = 0;
+    for (int l = 2; l <= Lm; l++) { // forward phase giving layer l
+        const int G = (h->ld[l] + 63) / 64, gw = G * 64, k4n = m.kr[l - 1] / 4;
+        if (G > 16 || 4 * gw > budget) return;
+        int ks = 16 / G;
+        if (ks > k4n) ks = k4n;
+        if (ks > budget / (4 * gw)) ks = budget / (4 * gw);
+        m.ks_fwd[l] = ks;
+        scratch = ks * 4 * gw > scratch ? ks * 4 * gw : scratch;
+    }
+    for (int l = Lm - 1; l >= 1; l--) { // backward phase giving delta_l
+        const int G = (m.kr[l] + 63) / 64, gw = G * 64, k4n = m.kr[l + 1] / 4;
+        if (G > 16 || 4 * gw > budget) return;
+        int ks = 16 / G;
+        if (ks > k4n) ks = k4n;
+        if (ks > budget / (4 * gw)) ks = budget / (4 * gw);
+        m.ks_bwd[l] = ks;
+        scratch = ks * 4 * gw > scratch ? ks * 4 * gw : scratch;
+    }
+    off += scratch + 128; // + slack: the last weight row's column-group reads run past the image
+    h->mid4_lds_bytes = (size_t)off * sizeof(float);
+    for (int l = 1; l < Lm; l++) { m.W[l] = h->W + h->w_off[l]; m.act[l] = h->act[l]; }
+    for (int l = 1; l <= Lm; l++) m.delta[l] = h->delta[l];
+    m.last_act = h->last_act;
+    for (int bwd = 0; bwd < 2; bwd++) {
+        if (hipFuncSetAttribute(mid4_function(h->inner_act, h->out_kind, bwd != 0),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mid4_lds_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+    }
+    h->mid4 = true;
 }
 
 // forward of the fused path; backward = also delta_1..delta_{L-1}
@@ -301,9 +400,20 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
     f.M = B_pad; f.N = h->ld[1]; f.K = h->ld[0];
     f.m_true = B; f.n_true = h->dims[1];
     f.act = h->inner_act; f.apply_act = 1;
+    f.tiling = make_xcd_tiling(f.M / 16, f.N / 16);
     {
         ScopedTimer tm(h, GNN_K_FWD_GEMM0);
-        hipLaunchKernelGGL((fwd_first_kernel<FIRST_NW>), dim3(f.N / 16, f.M / 16), dim3(FIRST_NW * 64), 0, h->stream, f);
+        hipLaunchKernelGGL((fwd_first_kernel<FIRST_NW>), dim3(f.tiling.blocks()), dim3(FIRST_NW * 64), 0, h->stream, f);
+    }
+    if (h->mid4) {
+        Mid4Params m4 = h->mid4p;
+        m4.Y = y; m4.ldy = h->ld[h->L - 1];
+        m4.prob = want_prob ? h->prob : nullptr;
+        m4.loss = want_loss ? h->lossv : nullptr;
+        m4.label = want_label ? h->labels : nullptr;
+        m4.B = B;
+        mid4_dispatch(h->inner_act, h->out_kind, backward, m4, pad_up(B) / 4, h->mid4_lds_bytes, h->stream); // every padded row: rows >= B become zeros
+        return;
     }
     MidParams m = h->mid;
     m.Y = y; m.ldy = h->ld[h->L - 1];

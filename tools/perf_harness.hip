@@ -1,0 +1,164 @@
+// perf_harness.hip -- development harness (not shipped): runs the fused step kernels on the
+// 784-300-100-10 / B=128 shapes with random data, times them with HIP events and prints the
+// middle kernel's phase stamps (STAMP build).
+#include "../graph-neural-net_amd/csrc/middle4_kernel.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+using namespace gnn;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+int main(int argc, char **argv) {
+    const int L = 4, dims[4] = {784, 300, 100, 10};
+    int B = argc > 1 ? atoi(argv[1]) : 128;
+    int ld[4]; for (int i = 0; i < L; i++) ld[i] = pad_up(dims[i]);
+    const int Bp = pad_up(B);
+    size_t woff[3], np = 0; for (int l = 0; l < 3; l++) { woff[l] = np; np += (size_t)ld[l] * ld[l + 1]; }
+    float *W, *V, *G, *act[4], *delta[4], *Y, *lossv; int32_t *labels; unsigned long long *stamps;
+    CK(hipMalloc(&W, np * 4)); CK(hipMalloc(&V, np * 4)); CK(hipMalloc(&G, np * 4));
+    std::vector<float> hw(np, 0.f);
+    for (int l = 0; l < 3; l++) for (int i = 0; i < dims[l]; i++) for (int j = 0; j < dims[l + 1]; j++)
+        hw[woff[l] + (size_t)i * ld[l + 1] + j] = (rand() / (float)RAND_MAX - 0.5f) * 0.2f;
+    CK(hipMemcpy(W, hw.data(), np * 4, hipMemcpyHostToDevice)); CK(hipMemset(V, 0, np * 4));
+    for (int l = 0; l < L; l++) { CK(hipMalloc(&act[l], (size_t)Bp * ld[l] * 4)); CK(hipMemset(act[l], 0, (size_t)Bp * ld[l] * 4));
+                                  CK(hipMalloc(&delta[l], (size_t)Bp * ld[l] * 4)); CK(hipMemset(delta[l], 0, (size_t)Bp * ld[l] * 4)); }
+    std::vector<float> hx((size_t)Bp * ld[0], 0.f), hy((size_t)Bp * ld[3], 0.f);
+    for (int b = 0; b < B; b++) { for (int i = 0; i < dims[0]; i++) hx[(size_t)b * ld[0] + i] = rand() / (float)RAND_MAX; hy[(size_t)b * ld[3] + rand() % 10] = 1.f; }
+    CK(hipMemcpy(act[0], hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&Y, hy.size() * 4)); CK(hipMemcpy(Y, hy.data(), hy.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&lossv, Bp * 4)); CK(hipMalloc(&labels, Bp * 4)); CK(hipMalloc(&stamps, 4096 * 8)); CK(hipMemset(stamps, 0, 4096 * 8));
+
+    FwdFirstParams f{}; f.A = act[0]; f.lda = ld[0]; f.W = W; f.ldw = ld[1]; f.C = act[1]; f.ldc = ld[1];
+    f.M = Bp; f.N = ld[1]; f.K = ld[0]; f.m_true = B; f.n_true = dims[1]; f.act = 0; f.apply_act = 1; f.tiling = make_xcd_tiling(f.M / 16, f.N / 16);
+    MidParams m{}; m.L = L; int off = 0, maxld = 0;
+    for (int l = 0; l < L; l++) { m.d[l] = dims[l]; m.ld[l] = ld[l]; }
+    for (int l = 1; l < 3; l++) { m.off_act[l] = off; off += 16 * (ld[l] + 4); }
+    m.off_logits = off; off += 16 * (ld[3] + 4);
+    for (int l = 1; l < L; l++) maxld = std::max(maxld, ld[l]);
+    m.off_da = off; off += 16 * (maxld + 4); m.off_db = off; off += 16 * (maxld + 4);
+    m.kp_fwd[2] = argc > 2 ? atoi(argv[2]) : 2; m.kp_fwd[3] = 7; m.kp_bwd[2] = 1; m.kp_bwd[1] = argc > 3 ? atoi(argv[3]) : 2;
+    m.off_scratch = off; off += 3 * 16 * 304;
+    for (int l = 1; l < 3; l++) { m.W[l] = W + woff[l]; m.act[l] = act[l]; }
+    for (int l = 1; l < L; l++) m.delta[l] = delta[l];
+    m.Y = Y; m.ldy = ld[3]; m.loss = lossv; m.label = labels; m.B = B; m.backward = 1; m.stamps = stamps;
+    size_t lds = (size_t)off * 4;
+    CK(hipFuncSetAttribute((const void *)&middle_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)&middle_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GradParams g{}; g.n_layers = 3; int tiles = 0;
+    for (int l = 0; l < 3; l++) { GradLayer &gl = g.layer[l]; gl.A = act[l]; gl.lda = ld[l]; gl.D = delta[l + 1]; gl.ldd = ld[l + 1];
+        gl.W = W + woff[l]; gl.V = V + woff[l]; gl.G = G + woff[l]; gl.M = ld[l]; gl.N = ld[l + 1]; gl.tiling = make_xcd_tiling((gl.M + 31) / 32, (gl.N + 31) / 32); gl.block_begin = tiles; tiles += gl.tiling.blocks(); }
+    g.K = Bp; g.step_over_b = 0.0125f / B; g.momentum = 0.9f;
+
+    // middle4 plan (same arithmetic as plan_mid4 in gnn_mlp.hip)
+    Mid4Params m4{}; m4.L = L; size_t lds4 = 0;
+    {
+        for (int l = 0; l < L; l++) { m4.d[l] = dims[l]; m4.ld[l] = ld[l]; m4.kr[l] = (dims[l] + 3) / 4 * 4; }
+        int o = 0; auto take = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
+        for (int l = 1; l < 3; l++) m4.off_w[l] = take(m4.kr[l] * (ld[l + 1] + 1));
+        for (int l = 1; l < 3; l++) m4.off_act[l] = take(4 * (ld[l] + 4));
+        m4.off_logits = take(4 * (ld[3] + 4));
+        for (int l = 2; l <= 3; l++) m4.off_dl[l] = take(4 * (ld[l] + 4));
+        m4.off_y = take(4 * ld[3]); m4.off_scratch = o;
+        m4.w_total4 = 0;
+        for (int l = 1; l < 3; l++) { int c4 = ld[l + 1] / 4; m4.w_begin4[l] = m4.w_total4; m4.w_total4 += m4.kr[l] * c4; m4.w_inv_c4[l] = (unsigned)(((1ull << 32) + c4 - 1) / c4); }
+        int budget = 160 * 1024 / 4 - 128 - o, scratch = 0;
+        for (int l = 2; l <= 3; l++) { int G = (ld[l] + 63) / 64, gw = G * 64, k4n = m4.kr[l - 1] / 4, ks = std::min(std::min(16 / G, k4n), budget / (4 * gw)); m4.ks_fwd[l] = ks; scratch = std::max(scratch, ks * 4 * gw); }
+        for (int l = 2; l >= 1; l--) { int G = (m4.kr[l] + 63) / 64, gw = G * 64, k4n = m4.kr[l + 1] / 4, ks = std::min(std::min(16 / G, k4n), budget / (4 * gw)); m4.ks_bwd[l] = ks; scratch = std::max(scratch, ks * 4 * gw); }
+        o += scratch + 128; lds4 = (size_t)o * 4;
+        printf("middle4: LDS %zu bytes, ks_fwd = %d %d, ks_bwd = %d %d\n", lds4, m4.ks_fwd[2], m4.ks_fwd[3], m4.ks_bwd[2], m4.ks_bwd[1]);
+        for (int l = 1; l < 3; l++) { m4.W[l] = W + woff[l]; m4.act[l] = act[l]; }
+        for (int l = 1; l < L; l++) m4.delta[l] = delta[l];
+        m4.Y = Y; m4.ldy = ld[3]; m4.loss = lossv; m4.label = labels; m4.B = B; m4.stamps = stamps;
+        CK(hipFuncSetAttribute((const void *)&middle4_kernel<0, 0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        CK(hipFuncSetAttribute((const void *)&middle4_kernel<0, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    }
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time_it = [&](const char *name, int n, auto fn) {
+        for (int i = 0; i < 20; i++) fn();
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < n; i++) fn();
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-28s %8.2f us per call\n", name, ms * 1000.f / n);
+    };
+    auto k_first = [&]() { hipLaunchKernelGGL((fwd_first_kernel<8>), dim3(f.tiling.blocks()), dim3(512), 0, s, f); };
+    auto k_first16 = [&]() { hipLaunchKernelGGL((fwd_first_kernel<16>), dim3(f.tiling.blocks()), dim3(1024), 0, s, f); };
+    auto k_mid = [&]() { hipLaunchKernelGGL((middle_kernel<16, false>), dim3(Bp / 16), dim3(1024), lds, s, m); };
+    auto k_mid_stamp = [&]() { hipLaunchKernelGGL((middle_kernel<16, true>), dim3(Bp / 16), dim3(1024), lds, s, m); };
+    auto k_grad = [&]() { hipLaunchKernelGGL((grad_update_kernel<true>), dim3(tiles), dim3(256), 0, s, g); };
+    auto k_grad_nf = [&]() { hipLaunchKernelGGL((grad_update_kernel<false>), dim3(tiles), dim3(256), 0, s, g); };
+    time_it("fwd_first<8>", 500, k_first);
+    time_it("fwd_first<16>", 500, k_first16);
+    time_it("fwd_first<8,ACT=leaky>", 500, [&]() { hipLaunchKernelGGL((fwd_first_kernel<8, false, 0>), dim3(f.tiling.blocks()), dim3(512), 0, s, f); });
+    time_it("middle<16>", 500, k_mid);
+    auto k_mid4 = [&]() { hipLaunchKernelGGL((middle4_kernel<0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
+    time_it("middle4", 500, k_mid4);
+    time_it("step with middle4", 500, [&]() { k_first(); k_mid4(); k_grad(); });
+    time_it("grad_update<fused>", 500, k_grad);
+    time_it("grad_update<store G>", 500, k_grad_nf);
+    time_it("whole step (3 launches)", 500, [&]() { k_first(); k_mid(); k_grad(); });
+    {   // 50 steps captured in one hipGraph: per-step time without host launch limits
+        hipGraph_t graph; hipGraphExec_t exec;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < 50; i++) { k_first(); k_mid(); k_grad(); }
+        CK(hipStreamEndCapture(s, &graph));
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (int i = 0; i < 3; i++) CK(hipGraphLaunch(exec, s));
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < 10; i++) CK(hipGraphLaunch(exec, s));
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-28s %8.2f us per step\n", "graph replay (50 steps/graph)", ms * 1000.f / 500);
+    }
+    {
+        f.stamps = stamps; g.stamps = stamps;
+        for (int rep = 0; rep < 2; rep++) {
+        if (rep) hipLaunchKernelGGL((fwd_first_kernel<8, true, 0>), dim3(f.tiling.blocks()), dim3(512), 0, s, f);
+        else hipLaunchKernelGGL((fwd_first_kernel<8, true>), dim3(f.tiling.blocks()), dim3(512), 0, s, f);
+        CK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> hs(f.tiling.blocks() * 8);
+        CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        printf("fwd_first stamps (%s):", rep ? "ACT templated" : "ACT runtime");
+        for (int w : {0, 1, 80, 150}) printf(" wg%d: loads+mfma=%llu red=%llu epi=%llu |", w, hs[w*8+1]-hs[w*8], hs[w*8+2]-hs[w*8+1], hs[w*8+3]-hs[w*8+2]);
+        printf("\n");
+        }
+        hipLaunchKernelGGL((fwd_first_kernel<8, true>), dim3(f.tiling.blocks()), dim3(512), 0, s, f);
+        CK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> hs(f.tiling.blocks() * 8);
+        CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int w = 0; w < 0; w++) { t0 = std::min(t0, hs[w * 8]); t1 = std::max(t1, hs[w * 8 + 3]); }
+        printf("fwd_first stamps: kernel span %llu cycles;", t1 - t0);
+        for (int w : {0, 1, 75, 150}) printf(" wg%d: start+%llu loads+mfma=%llu red=%llu epi=%llu |", w, hs[w*8]-t0, hs[w*8+1]-hs[w*8], hs[w*8+2]-hs[w*8+1], hs[w*8+3]-hs[w*8+2]);
+        printf("\n");
+        hipLaunchKernelGGL((grad_update_kernel<true, true>), dim3(tiles), dim3(256), 0, s, g);
+        CK(hipStreamSynchronize(s));
+        hs.resize(tiles * 8);
+        CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        t0 = ~0ull; t1 = 0;
+        for (int w = 0; w < 0; w++) { t0 = std::min(t0, hs[w * 8]); t1 = std::max(t1, hs[w * 8 + 3]); }
+        printf("grad_update stamps: kernel span %llu cycles;", t1 - t0);
+        for (int w : {0, 1, 128, 249, 281, 329}) printf(" wg%d: start+%llu load=%llu mfma=%llu epi=%llu |", w, hs[w*8]-t0, hs[w*8+1]-hs[w*8], hs[w*8+2]-hs[w*8+1], hs[w*8+3]-hs[w*8+2]);
+        printf("\n");
+    }
+    {
+        hipLaunchKernelGGL((middle4_kernel<0, 0, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
+        CK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> hs(2 * 32 * 16);
+        CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        for (int wg : {0, 9, 31, 32, 41, 63}) printf("middle4 stamps wg %d%s: load+stage=%llu fwdL2=%llu fwdL3=%llu output=%llu bwd2=%llu bwd1=%llu total=%llu\n", wg % 32, wg >= 32 ? " (2nd pass)" : "",
+            hs[wg*16+1]-hs[wg*16], hs[wg*16+6]-hs[wg*16+1], hs[wg*16+7]-hs[wg*16+6], hs[wg*16+3]-hs[wg*16+2], hs[wg*16+12]-hs[wg*16+3], hs[wg*16+11]-hs[wg*16+12], hs[wg*16+4]-hs[wg*16]);
+    }
+    k_mid_stamp(); CK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> hs(Bp / 16 * 16);
+    CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+    const char *names[] = {"stage A1", "gemm L2", "epi L2", "gemm L3", "epi L3", "output", "gemm d2", "epi d2", "gemm d1", "epi d1"};
+    for (int wg : {0, Bp / 16 - 1}) {
+        printf("middle stamps, workgroup %d (cycles @ memtime):", wg);
+        for (int i = 1; i <= 10; i++) printf(" %s=%llu", names[i - 1], hs[wg * 16 + i] - hs[wg * 16 + i - 1]);
+        printf(" total=%llu\n", hs[wg * 16 + 10] - hs[wg * 16]);
+    }
+    return 0;
+}

@@ -1,0 +1,96 @@
+// stream_probe.hip -- diagnostic: how fast can ONE workgroup pull a 136 KB weight matrix into
+// registers/LDS right after another kernel rewrote it (cold L2), as a function of grid size,
+// sharing across workgroups and start rotation.  Prints cycles (s_memtime) per workgroup.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1;} } while (0)
+
+__global__ void touch(float4 *w, int n4, float v) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) w[i] = make_float4(v, v, v, v);
+}
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(NT) void stream(const float4 *w, int n4, int stride4, int rotate, unsigned long long *out, float *sink) {
+    extern __shared__ float4 lds[];
+    const int t = threadIdx.x;
+    const float4 *src = w + (size_t)blockIdx.x * stride4;
+    const int rot = rotate ? (int)(((long)n4 * ((blockIdx.x >> 3) & 3)) >> 2) : 0;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    float4 acc = make_float4(0, 0, 0, 0);
+    constexpr int MAXF = 9;
+    for (int base = 0; base < n4; base += MAXF * NT) {
+        float4 v[MAXF];
+#pragma unroll
+        for (int i = 0; i < MAXF; i++) {
+            int idx = base + i * NT + t;
+            if (idx < n4) { idx += rot; if (idx >= n4) idx -= n4; v[i] = src[idx]; } else v[i] = make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXF; i++) {
+            int idx = base + i * NT + t;
+            if (MODE == 1) { if (idx < n4) lds[idx] = v[i]; }
+            else if (MODE == 2 || MODE == 3) { // [row][113] image, rows of 28 float4
+                if (idx < n4) {
+                    const int row = idx / 28, col = (idx - row * 28) * 4;
+                    float *dst = reinterpret_cast<float *>(lds) + row * 113 + col;
+                    if (MODE == 2) { dst[0] = v[i].x; dst[1] = v[i].y; dst[2] = v[i].z; dst[3] = v[i].w; }
+                    else {
+                        const int r = (t >> 3) & 3; // lanes l, l+8, l+16, l+24 write different components
+                        const float e0 = r == 0 ? v[i].x : r == 1 ? v[i].y : r == 2 ? v[i].z : v[i].w;
+                        const float e1 = r == 0 ? v[i].y : r == 1 ? v[i].z : r == 2 ? v[i].w : v[i].x;
+                        const float e2 = r == 0 ? v[i].z : r == 1 ? v[i].w : r == 2 ? v[i].x : v[i].y;
+                        const float e3 = r == 0 ? v[i].w : r == 1 ? v[i].x : r == 2 ? v[i].y : v[i].z;
+                        dst[r] = e0; dst[(r + 1) & 3] = e1; dst[(r + 2) & 3] = e2; dst[(r + 3) & 3] = e3;
+                    }
+                }
+            }
+            else { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+        }
+    }
+    __syncthreads();
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (t == 0) out[blockIdx.x] = t1 - t0;
+    if (acc.x + acc.y + acc.z + acc.w == 1234.5f) *sink = acc.x;
+    if (MODE == 1 && lds[t].x == 1234.5f) *sink = 1.f;
+}
+
+int main() {
+    const int n4 = 300 * 112 / 4 + 100 * 16 / 4; // 8800 float4 = 137.5 KB
+    float4 *w; unsigned long long *out; float *sink;
+    CK(hipMalloc(&w, (size_t)n4 * 16 * 256)); CK(hipMalloc(&out, 256 * 8)); CK(hipMalloc(&sink, 4));
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    CK(hipFuncSetAttribute((const void *)&stream<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, n4 * 16));
+    CK(hipFuncSetAttribute((const void *)&stream<1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, n4 * 16 + 4096));
+    CK(hipFuncSetAttribute((const void *)&stream<1024, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, n4 * 16 + 4096));
+    auto run = [&](const char *name, int grid, int stride4, int rotate, int variant) {
+        std::vector<unsigned long long> h(grid);
+        unsigned long long best_med = ~0ull, mx = 0;
+        for (int rep = 0; rep < 5; rep++) {
+            hipLaunchKernelGGL(touch, dim3(256), dim3(256), 0, s, w, stride4 ? n4 * grid : n4, (float)rep);
+            if (variant == 0) hipLaunchKernelGGL((stream<1024, 0>), dim3(grid), dim3(1024), 0, s, w, n4, stride4, rotate, out, sink);
+            if (variant == 1) hipLaunchKernelGGL((stream<1024, 1>), dim3(grid), dim3(1024), n4 * 16, s, w, n4, stride4, rotate, out, sink);
+            if (variant == 4) hipLaunchKernelGGL((stream<1024, 2>), dim3(grid), dim3(1024), n4 * 16 + 4096, s, w, n4, stride4, rotate, out, sink);
+            if (variant == 5) hipLaunchKernelGGL((stream<1024, 3>), dim3(grid), dim3(1024), n4 * 16 + 4096, s, w, n4, stride4, rotate, out, sink);
+            if (variant == 2) hipLaunchKernelGGL((stream<512, 0>), dim3(grid), dim3(512), 0, s, w, n4, stride4, rotate, out, sink);
+            if (variant == 3) hipLaunchKernelGGL((stream<256, 0>), dim3(grid), dim3(256), 0, s, w, n4, stride4, rotate, out, sink);
+            if (hipStreamSynchronize(s) != hipSuccess) { printf("sync failed\n"); return; }
+            (void)hipMemcpy(h.data(), out, grid * 8, hipMemcpyDeviceToHost);
+            std::sort(h.begin(), h.end());
+            best_med = std::min(best_med, h[grid / 2]); mx = h[grid - 1];
+        }
+        printf("%-52s grid %3d: median %6llu cycles (%.1f B/clk), max(last rep) %6llu\n", name, grid, best_med, n4 * 16.0 / best_med, mx);
+    };
+    for (int grid : {32}) {
+        run("shared, to LDS [row][113] 4 x b32 writes", grid, 0, 0, 4);
+        run("shared, to LDS [row][113] 4 x b32 rotated comps", grid, 0, 0, 5);
+        run("shared 137KB, to registers, 1024 thr", grid, 0, 0, 0);
+        run("shared 137KB, to registers, 1024 thr, rotated", grid, 0, 1, 0);
+        run("shared 137KB, to LDS (b128 writes), 1024 thr", grid, 0, 0, 1);
+        run("shared 137KB, to registers, 512 thr", grid, 0, 0, 2);
+        run("shared 137KB, to registers, 256 thr", grid, 0, 0, 3);
+        run("private 137KB each, to registers, 1024 thr", grid, n4, 0, 0);
+    }
+    return 0;
+}
