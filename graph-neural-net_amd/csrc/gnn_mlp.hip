@@ -74,6 +74,7 @@ struct gnn_mlp {
     bool mid4 = false;        // middle4_kernel (LDS-resident weights) instead of middle_kernel
     Mid4Params mid4p{};
     size_t mid4_lds_bytes = 0;
+    const void *mid4_fn[2] = {nullptr, nullptr}; // [backward]
 
     bool timing = false;
     TimerClass timers[3];
@@ -298,34 +299,39 @@ void plan_fused(gnn_mlp *h) {
 }
 
 // ---- middle4_kernel plan ----------------------------------------------------------------------
-template <int ACT, int OUTK, bool BWD> const void *mid4_fn() { return reinterpret_cast<const void *>(&middle4_kernel<ACT, OUTK, BWD>); }
-template <int ACT, int OUTK, bool BWD> void mid4_launch(const Mid4Params &p, int grid, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((middle4_kernel<ACT, OUTK, BWD>), dim3(grid), dim3(1024), lds, s, p);
-}
-#define MID4_DISPATCH(CALL)                                                                     \
-    switch (act * 4 + outk * 2 + (bwd ? 1 : 0)) {                                               \
-    case 0: CALL(0, 0, false); break; case 1: CALL(0, 0, true); break;                          \
-    case 2: CALL(0, 1, false); break; case 3: CALL(0, 1, true); break;                          \
-    case 4: CALL(1, 0, false); break; case 5: CALL(1, 0, true); break;                          \
-    case 6: CALL(1, 1, false); break; case 7: CALL(1, 1, true); break;                          \
-    case 8: CALL(2, 0, false); break; case 9: CALL(2, 0, true); break;                          \
-    case 10: CALL(2, 1, false); break; case 11: CALL(2, 1, true); break;                        \
-    case 12: CALL(3, 0, false); break; case 13: CALL(3, 0, true); break;                        \
-    case 14: CALL(3, 1, false); break; case 15: CALL(3, 1, true); break;                        \
-    case 16: CALL(4, 0, false); break; case 17: CALL(4, 0, true); break;                        \
-    case 18: CALL(4, 1, false); break; default: CALL(4, 1, true); break;                        \
+// kernel table: [shape policy][activation][output kind][backward]
+template <class SH, int OUTK> const void *mid4_fn_sh(int act, bool bwd) {
+#define GNN_M4(A) (bwd ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true>) \
+                       : reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, false>))
+    switch (act) {
+    case 0: return GNN_M4(0);
+    case 1: return GNN_M4(1);
+    case 2: return GNN_M4(2);
+    case 3: return GNN_M4(3);
+    default: return GNN_M4(4);
     }
-const void *mid4_function(int act, int outk, bool bwd) {
-    const void *f = nullptr;
-#define CALL(A, O, B) f = mid4_fn<A, O, B>()
-    MID4_DISPATCH(CALL)
-#undef CALL
-    return f;
+#undef GNN_M4
 }
-void mid4_dispatch(int act, int outk, bool bwd, const Mid4Params &p, int grid, size_t lds, hipStream_t s) {
-#define CALL(A, O, B) mid4_launch<A, O, B>(p, grid, lds, s)
-    MID4_DISPATCH(CALL)
-#undef CALL
+// shapes with compile-time plans (BASELINE.json configs that take the fused path)
+using ShapeMnistA = StaticShape<784, 300, 100, 10>;
+using ShapeMnistB = StaticShape<784, 100, 50, 10>;
+
+template <class SH> bool shape_matches(const gnn_mlp *h) {
+    constexpr int n = (int)(sizeof(SH::kDims) / sizeof(int));
+    if (h->L != n) return false;
+    for (int i = 0; i < n; i++) if (h->dims[i] != SH::kDims[i]) return false;
+    return true;
+}
+
+const void *mid4_function(const gnn_mlp *h, bool bwd) {
+    const char *env = getenv("GNN_MLP_STATIC");
+    const bool allow_static = !(env && !strcmp(env, "0"));
+    if (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE) {
+        if (shape_matches<ShapeMnistA>(h)) return mid4_fn_sh<ShapeMnistA, 0>(h->inner_act, bwd);
+        if (shape_matches<ShapeMnistB>(h)) return mid4_fn_sh<ShapeMnistB, 0>(h->inner_act, bwd);
+    }
+    return h->out_kind == GNN_OUT_SOFTMAX_CE ? mid4_fn_sh<RuntimeShape, 0>(h->inner_act, bwd)
+                                             : mid4_fn_sh<RuntimeShape, 1>(h->inner_act, bwd);
 }
 
 void plan_mid4(gnn_mlp *h) {
@@ -335,53 +341,16 @@ void plan_mid4(gnn_mlp *h) {
     const int L = h->L, Lm = L - 1;
     Mid4Params &m = h->mid4p;
     m = Mid4Params{};
-    m.L = L;
-    for (int l = 0; l < L; l++) { m.d[l] = h->dims[l]; m.ld[l] = h->ld[l]; m.kr[l] = (h->dims[l] + 3) / 4 * 4; }
-    int off = 0;
-    auto take = [&](int n) { const int o = off; off += (n + 3) / 4 * 4; return o; };
-    for (int l = 1; l < Lm; l++) m.off_w[l] = take(m.kr[l] * (h->ld[l + 1] + 1));
-    for (int l = 1; l < Lm; l++) m.off_act[l] = take(4 * (h->ld[l] + 4));
-    m.off_logits = take(4 * (h->ld[Lm] + 4));
-    for (int l = 2; l <= Lm; l++) m.off_dl[l] = take(4 * (h->ld[l] + 4));
-    m.off_y = take(4 * h->ld[Lm]);
-    m.off_scratch = off;
-    m.w_total4 = 0;
-    for (int l = 1; l < Lm; l++) {
-        const int c4 = h->ld[l + 1] / 4;
-        m.w_begin4[l] = m.w_total4;
-        m.w_total4 += m.kr[l] * c4;
-        m.w_inv_c4[l] = (unsigned)(((1ull << 32) + c4 - 1) / c4);
-    }
-    if (m.w_total4 >= (1 << 20)) return; // the reciprocal division is exact well beyond this
-    const int budget = (160 * 1024) / 4 - 128 - off; // floats left for the K-split partials
-    if (budget < 0) return;
-    int scratch = 0;
-    for (int l = 2; l <= Lm; l++) { // forward phase giving layer l
-        const int G = (h->ld[l] + 63) / 64, gw = G * 64, k4n = m.kr[l - 1] / 4;
-        if (G > 16 || 4 * gw > budget) return;
-        int ks = 16 / G;
-        if (ks > k4n) ks = k4n;
-        if (ks > budget / (4 * gw)) ks = budget / (4 * gw);
-        m.ks_fwd[l] = ks;
-        scratch = ks * 4 * gw > scratch ? ks * 4 * gw : scratch;
-    }
-    for (int l = Lm - 1; l >= 1; l--) { // backward phase giving delta_l
-        const int G = (m.kr[l] + 63) / 64, gw = G * 64, k4n = m.kr[l + 1] / 4;
-        if (G > 16 || 4 * gw > budget) return;
-        int ks = 16 / G;
-        if (ks > k4n) ks = k4n;
-        if (ks > budget / (4 * gw)) ks = budget / (4 * gw);
-        m.ks_bwd[l] = ks;
-        scratch = ks * 4 * gw > scratch ? ks * 4 * gw : scratch;
-    }
-    off += scratch + 128; // + slack: the last weight row's column-group reads run past the image
-    h->mid4_lds_bytes = (size_t)off * sizeof(float);
+    m.plan = make_mid4_plan(h->dims.data(), L);
+    if (!m.plan.ok) return;
+    h->mid4_lds_bytes = (size_t)m.plan.lds_floats * sizeof(float);
     for (int l = 1; l < Lm; l++) { m.W[l] = h->W + h->w_off[l]; m.act[l] = h->act[l]; }
     for (int l = 1; l <= Lm; l++) m.delta[l] = h->delta[l];
     m.last_act = h->last_act;
     for (int bwd = 0; bwd < 2; bwd++) {
-        if (hipFuncSetAttribute(mid4_function(h->inner_act, h->out_kind, bwd != 0),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mid4_lds_bytes) != hipSuccess) {
+        h->mid4_fn[bwd] = mid4_function(h, bwd != 0);
+        if (hipFuncSetAttribute(h->mid4_fn[bwd], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)h->mid4_lds_bytes) != hipSuccess) {
             (void)hipGetLastError();
             return;
         }
@@ -412,7 +381,9 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
         m4.loss = want_loss ? h->lossv : nullptr;
         m4.label = want_label ? h->labels : nullptr;
         m4.B = B;
-        mid4_dispatch(h->inner_act, h->out_kind, backward, m4, pad_up(B) / 4, h->mid4_lds_bytes, h->stream); // every padded row: rows >= B become zeros
+        void *args[] = {&m4};
+        // every padded row is processed: rows >= B become zeros
+        (void)hipLaunchKernel(h->mid4_fn[backward ? 1 : 0], dim3(pad_up(B) / 4), dim3(1024), args, h->mid4_lds_bytes, h->stream);
         return;
     }
     MidParams m = h->mid;

@@ -2,41 +2,114 @@
 // workgroup, with every middle weight matrix resident in LDS.
 //
 // Why four rows: the chain (SCE:172-198 forward, SCE:249-251 output delta, SCE:262-278 backward)
-// is per-sample independent, and a workgroup must stream ALL middle weights (W_1 is 136 KB for
-// 784-300-100-10) through its CU.  A CU pulls only ~10-15 B/clk from beyond L2 and ~30 B/clk
-// from L2, and every kernel starts with a cold L2, so the step time of this kernel is the weight
-// stream.  With B/4 workgroups, four of them share an XCD (blocks b and b+8 land on one L2):
-// each starts its stream at a different quarter, so three quarters of its bytes are L2 hits.
-// The weights are read ONCE into LDS ([k][ld+1] image, odd row stride) and serve both the
-// forward product (lanes along n: consecutive addresses) and the backward product with W^T
-// (lanes along the image's rows: stride ld+1, conflict-free because it is odd).
+// is per-sample independent, and a workgroup must pull ALL middle weights (W_1 is 120 KB for
+// 784-300-100-10) through its CU.  Every kernel starts with a cold L2, so the weights are read
+// from memory exactly ONCE per workgroup, all loads in flight together, into an LDS image that
+// then serves both the forward product (A . W) and the backward product (delta . W^T).  With
+// B/4 workgroups four of them share an XCD's L2 (blocks b and b+8): each starts its stream at a
+// different quarter, so three quarters of its bytes are L2 hits.
+//
+// LDS image of W_l: [k][lw] floats, lw = 4*(odd) >= round_up(d_{l+1},4) + 4; only the logical
+// columns are copied (120 KB instead of 134 KB for W_1).  The row stride is a multiple of 4
+// floats, so the stream is written with ds_write_b128, and lw/4 is odd, so
+//   forward : lane l reads W[k][n0+l]              -- consecutive addresses, conflict-free b32
+//   backward: lane l reads W[n0+l][4q..4q+3] (b128) -- 16 lanes hit 16 different 16-B slots
 //
 // MFMA: v_mfma_f32_4x4x1_16b_f32 -- 16 blocks of (4x1).(1x4) per instruction.  Every block gets
-// the same A column (the 4 batch rows' activations at k; lane l supplies row l&3) and its own
-// 4 B values (lane l supplies W[k][n0+l]), so one instruction is the rank-1 update
-// Z[0..3][n0..n0+63] += a[0..3] (x) W[k][n0..n0+63]; accumulator register i of lane l is
-// Z[row i][n0+l].  Exact f32, same rate per FLOP as the 16x16x4 form, no padding rows.
+// the same A column (the 4 batch rows' value at k; lane l supplies row l&3) and its own 4 B
+// values (lane l supplies B[k][n0+l]), so one instruction is the rank-1 update
+// Z[0..3][n0..n0+63] += a[0..3] (x) B[k][n0..n0+63]; accumulator register i of lane l is
+// Z[row i][n0+l].  Exact f32, same FLOP rate as the 16x16x4 form, no padding rows.
+//
+// The kernel is written once over a "shape" policy: RuntimeShape reads the plan from the kernel
+// arguments (any net that fits), StaticShape<d0,d1,...> makes every extent, LDS offset and K
+// split a compile-time constant.  At this problem size a workgroup's critical path is a few
+// thousand instructions, so kernarg loads, integer divisions and layer loops with runtime
+// bounds are a large share of the step; the static instantiations remove them.
 #pragma once
 #include "fused_kernels.h"
 
 namespace gnn {
 
-struct Mid4Params {
+// ---- LDS plan, computed identically on the host (runtime) and at compile time -----------------
+struct Mid4Plan {
     int L;
-    int d[MAX_LAYERS], ld[MAX_LAYERS];
-    int kr[MAX_LAYERS];          // rows of layer l kept in LDS / contracted over: round_up(d[l], 4)
+    int d[MAX_LAYERS], ld[MAX_LAYERS], kr[MAX_LAYERS]; // kr = round_up(d, 4): rows kept / contracted
+    int lw[MAX_LAYERS];      // row stride of weight image l: 4*(odd) floats >= kr[l+1] + 4
+    int off_w[MAX_LAYERS];   // weight images l = 1..L-2: [kr[l]][lw[l]], only kr[l+1] columns are copied
+    int off_act[MAX_LAYERS]; // activation images l = 1..L-2: [4][ld[l]+4]
+    int off_dl[MAX_LAYERS];  // delta images l = 2..L-1: [4][ld[l]+4]
+    int off_logits, off_y, off_scratch;
+    int ks_fwd[MAX_LAYERS];  // K splits of the product giving layer l (l = 2..L-1)
+    int ks_bwd[MAX_LAYERS];  // K splits of the product giving delta_l (l = 1..L-2)
+    int w_total4;            // float4s in all weight images
+    int w_begin4[MAX_LAYERS];
+    unsigned long long w_inv_c4[MAX_LAYERS]; // ceil(2^32 / c4) (2^32 itself when c4 = 1): row = (idx * inv) >> 32
+    int lds_floats;          // total dynamic LDS, floats
+    bool ok;
+};
+
+__host__ __device__ constexpr int mid4_min(int a, int b) { return a < b ? a : b; }
+
+__host__ __device__ constexpr Mid4Plan make_mid4_plan(const int *dims, int L) {
+    Mid4Plan m{};
+    m.L = L;
+    m.ok = false;
+    if (L < 3 || L > MAX_LAYERS) return m;
+    const int Lm = L - 1;
+    for (int l = 0; l < L; l++) {
+        m.d[l] = dims[l];
+        m.ld[l] = (dims[l] + PAD - 1) / PAD * PAD;
+        m.kr[l] = (dims[l] + 3) / 4 * 4;
+    }
+    int off = 0;
+    for (int l = 1; l < Lm; l++) {
+        int lw4 = m.kr[l + 1] / 4 + 1;
+        if (lw4 % 2 == 0) lw4++; // (row stride / 4) odd: b128 reads down a column of rows hit 16 different slots
+        m.lw[l] = 4 * lw4;
+        m.off_w[l] = off;
+        off += m.kr[l] * m.lw[l];
+    }
+    for (int l = 1; l < Lm; l++) { m.off_act[l] = off; off += 4 * (m.ld[l] + 4); }
+    m.off_logits = off; off += 4 * (m.ld[Lm] + 4);
+    for (int l = 2; l <= Lm; l++) { m.off_dl[l] = off; off += 4 * (m.ld[l] + 4); }
+    m.off_y = off; off += 4 * m.ld[Lm];
+    m.off_scratch = off;
+    m.w_total4 = 0;
+    for (int l = 1; l < Lm; l++) {
+        const int c4 = m.kr[l + 1] / 4; // float4s copied per row (the padding columns stay in HBM)
+        m.w_begin4[l] = m.w_total4;
+        m.w_total4 += m.kr[l] * c4;
+        m.w_inv_c4[l] = ((1ull << 32) + c4 - 1) / c4;
+    }
+    if (m.w_total4 >= (1 << 20)) return m;
+    const int budget = (160 * 1024) / 4 - 64 - off; // floats left for the K-split partials
+    if (budget <= 0) return m;
+    int scratch = 0;
+    for (int l = 2; l <= Lm; l++) {
+        const int G = (m.kr[l] + 63) / 64, gw = G * 64, k4n = m.kr[l - 1] / 4;
+        if (G > 16 || 4 * gw > budget) return m;
+        const int ks = mid4_min(mid4_min(16 / G, k4n), budget / (4 * gw));
+        m.ks_fwd[l] = ks;
+        if (ks * 4 * gw > scratch) scratch = ks * 4 * gw;
+    }
+    for (int l = Lm - 1; l >= 1; l--) {
+        const int G = (m.kr[l] + 63) / 64, gw = G * 64, k4n = m.kr[l + 1] / 4;
+        if (G > 16 || 4 * gw > budget) return m;
+        const int ks = mid4_min(mid4_min(16 / G, k4n), budget / (4 * gw));
+        m.ks_bwd[l] = ks;
+        if (ks * 4 * gw > scratch) scratch = ks * 4 * gw;
+    }
+    m.lds_floats = off + scratch + 64;
+    m.ok = true;
+    return m;
+}
+
+struct Mid4Params {
+    Mid4Plan plan;               // used by RuntimeShape only
     const float *W[MAX_LAYERS];  // global W_l, l = 1..L-2
     float *act[MAX_LAYERS];      // act[1] in; act[2..L-2] out
     float *delta[MAX_LAYERS];    // delta[1..L-1] out
-    int off_w[MAX_LAYERS];       // LDS float offsets: weight images l = 1..L-2, [kr[l]][ld[l+1]+1]
-    int off_act[MAX_LAYERS];     // activation images l = 1..L-2, [4][ld[l]+4]
-    int off_dl[MAX_LAYERS];      // delta images l = 2..L-1, [4][ld[l]+4]
-    int off_logits, off_y, off_scratch;
-    int w_total4;                // float4s in all weight images
-    int w_begin4[MAX_LAYERS];    // first float4 of layer l's image in that index space
-    unsigned w_inv_c4[MAX_LAYERS]; // ceil(2^32 / (ld[l+1]/4)): row = umulhi(idx, inv)
-    int ks_fwd[MAX_LAYERS];      // K splits of the product giving layer l (l = 2..L-1)
-    int ks_bwd[MAX_LAYERS];      // K splits of the product giving delta_l (l = 1..L-2)
     const float *Y; int ldy;
     float *prob; float *loss; int32_t *label;
     int B;
@@ -44,7 +117,19 @@ struct Mid4Params {
     unsigned long long *stamps;  // STAMP builds only
 };
 
-// 16-lane (one DPP row) butterfly: every lane ends with the reduction over its row of 16.
+struct RuntimeShape {
+    static constexpr bool is_static = false;
+};
+template <int... DIMS> struct StaticShape {
+    static constexpr bool is_static = true;
+    static constexpr int kDims[sizeof...(DIMS)] = {DIMS...};
+    __host__ __device__ static constexpr Mid4Plan make() {
+        constexpr int dims[sizeof...(DIMS)] = {DIMS...};
+        return make_mid4_plan(dims, (int)sizeof...(DIMS));
+    }
+};
+
+// ---- 16-lane (one DPP row) butterflies ----------------------------------------------------------
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
@@ -80,37 +165,38 @@ __device__ __forceinline__ void row16_argmax(float &v, int &ix) {
         if (STAMP && threadIdx.x == 0) p.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-// partial[ks][4][GW] = A_img[4 x Kpart] . B   for this wave's (column group g, K part ks)
-//   TRANS = false: B[k][n] = Wimg[k*ldw + n]          (forward,  n = output neuron)
-//   TRANS = true : B[k][n] = Wimg[n*ldw + k]          (backward, n = input neuron; n < n_rows)
+// partial[4][gw] (this wave's K part) = A_img[4 x Kpart] . B for column group n0..n0+63
+//   TRANS = false: B[k][n] = Wimg[k*ldw + n]   (forward:  n = neuron of the layer being produced)
+//   TRANS = true : B[k][n] = Wimg[n*ldw + k]   (backward: n = neuron of the layer receiving delta)
 template <bool TRANS>
 __device__ __forceinline__ void rowblock_product(const float *A_img, int lda, const float *Wimg, int ldw, int k4_begin,
                                                  int k4_end, int n0, int n_rows, float *partial, int gw, int lane) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const float *arow = A_img + (lane & 3) * lda;
     const float *wp;
-    int wstep;
     if (TRANS) {
         int n = n0 + lane;
         n = n < n_rows ? n : n_rows - 1; // columns past the image compute garbage nobody reads
         wp = Wimg + n * ldw;
-        wstep = 1;
     } else {
         wp = Wimg + n0 + lane;
-        wstep = ldw;
     }
-    // U groups of 4 k per trip: all 5*U LDS reads are issued before the first MFMA waits
+    // U groups of 4 k per trip: every LDS read of the trip is issued before the first MFMA waits
     constexpr int U = 4;
-    for (int kb = k4_begin; kb < k4_end; kb += U) { // k4_begin / k4_end are wave-uniform
-        f32x4 a[U];
-        float b[U][4];
+    for (int kb = k4_begin; kb < k4_end; kb += U) { // bounds are wave-uniform
+        f32x4 a[U], b[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int k4 = (kb + u < k4_end) ? kb + u : k4_end - 1; // tail: re-read the last group, weight 0
+            const bool in = kb + u < k4_end;
+            const int k4 = in ? kb + u : k4_end - 1; // tail: re-read the last group with weight 0
             a[u] = *reinterpret_cast<const f32x4 *>(arow + 4 * k4);
-            const float *w = wp + (4 * k4) * wstep;
-            b[u][0] = w[0]; b[u][1] = w[wstep]; b[u][2] = w[2 * wstep]; b[u][3] = w[3 * wstep];
-            if (kb + u >= k4_end) a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (TRANS) {
+                b[u] = *reinterpret_cast<const f32x4 *>(wp + 4 * k4);
+            } else {
+                const float *w = wp + (4 * k4) * ldw;
+                b[u] = (f32x4){w[0], w[ldw], w[2 * ldw], w[3 * ldw]};
+            }
+            if (!in) a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -128,41 +214,39 @@ __device__ __forceinline__ void rowblock_product(const float *A_img, int lda, co
     for (int i = 0; i < 4; i++) partial[i * gw + n0 + lane] = acc[i];
 }
 
-template <int ACT, int OUTK, bool BACKWARD, bool STAMP = false>
-__global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
+template <int ACT, int OUTK, bool BACKWARD, bool STAMP>
+__device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NW = 16, NT_ = 1024;
+    constexpr int NT_ = 1024;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // provably wave-uniform: scalar branches
     const int row0 = blockIdx.x * 4;
-    const int Lm = p.L - 1;
-    // STAMP builds run the body twice and stamp the SECOND pass too (slots 16..31 of the
-    // next record): the difference is what a cold instruction cache / cold L2 costs.
+    const int L = m.L, Lm = L - 1;
+    // STAMP builds run the body twice and stamp the second (warm) pass into the next record
     for (int pass = 0; pass < (STAMP ? 2 : 1); pass++) {
     if (STAMP && pass == 1) { __syncthreads(); p.stamps += 16 * gridDim.x; }
     GNN_STAMP4(0);
 
     // ---- phase 0: everything this block reads from memory, issued before anything waits ----
     {   // A_1 rows and expected rows
-        const int q1 = p.ld[1] / 4, qy = p.ld[Lm] / 4;
+        const int q1 = m.ld[1] / 4, qy = m.ld[Lm] / 4;
         for (int e = t; e < 4 * q1; e += NT_) {
-            const int m = e / q1, q = e - m * q1;
-            *reinterpret_cast<float4 *>(smem + p.off_act[1] + m * (p.ld[1] + 4) + q * 4) =
-                *reinterpret_cast<const float4 *>(p.act[1] + (size_t)(row0 + m) * p.ld[1] + q * 4);
+            const int mr = e / q1, q = e - mr * q1;
+            *reinterpret_cast<float4 *>(smem + m.off_act[1] + mr * (m.ld[1] + 4) + q * 4) =
+                *reinterpret_cast<const float4 *>(p.act[1] + (size_t)(row0 + mr) * m.ld[1] + q * 4);
         }
         if (p.Y) {
-            for (int e = NT_ - 1 - t; e < 4 * qy; e += NT_) { // the last threads, so that both loads fly together
-                const int m = e / qy, q = e - m * qy;
-                *reinterpret_cast<float4 *>(smem + p.off_y + m * p.ld[Lm] + q * 4) =
-                    *reinterpret_cast<const float4 *>(p.Y + (size_t)(row0 + m) * p.ldy + q * 4);
+            for (int e = NT_ - 1 - t; e < 4 * qy; e += NT_) { // the LAST threads: both loads fly together
+                const int mr = e / qy, q = e - mr * qy;
+                *reinterpret_cast<float4 *>(smem + m.off_y + mr * m.ld[Lm] + q * 4) =
+                    *reinterpret_cast<const float4 *>(p.Y + (size_t)(row0 + mr) * p.ldy + q * 4);
             }
         }
     }
     // weight images of every middle layer as ONE index space of float4s, all loads in flight at
-    // once; the start is rotated by the block's slot on its XCD so that the four blocks sharing
-    // an L2 fetch different quarters first
+    // once; the start is rotated by the block's slot on its XCD
     {
-        const int total = p.w_total4;
+        const int total = m.w_total4;
         const int rot = (int)(((long)total * ((blockIdx.x >> 3) & 3)) >> 2);
         constexpr int MAXF = 10;
         for (int base = 0; base < total; base += MAXF * NT_) {
@@ -171,29 +255,33 @@ __global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
 #pragma unroll
             for (int i = 0; i < MAXF; i++) {
                 int idx = base + i * NT_ + t;
-                dsto[i] = -1;
-                if (idx < total) {
-                    idx += rot;
-                    if (idx >= total) idx -= total;
-                    int l = 1;
+                const bool in = idx < total;
+                idx += rot;
+                if (idx >= total) idx -= total;
+                // which layer's image: resolved with compile-time layer numbers only (an array
+                // indexed by a runtime layer would become a dependent memory lookup); the selects
+                // pick an address, the load itself has ONE site so v[] stays in registers
+                const float *src = p.W[1];
+                int dst = -1;
 #pragma unroll
-                    for (int j = 2; j < MAX_LAYERS - 1; j++)
-                        if (j < Lm && idx >= p.w_begin4[j]) l = j;
-                    idx -= p.w_begin4[l];
-                    const int c4 = p.ld[l + 1] >> 2;
-                    const int row = (int)__umulhi((unsigned)idx, p.w_inv_c4[l]);
-                    const int col = (idx - row * c4) * 4;
-                    v[i] = *reinterpret_cast<const float4 *>(p.W[l] + (size_t)row * p.ld[l + 1] + col);
-                    dsto[i] = p.off_w[l] + row * (p.ld[l + 1] + 1) + col;
+                for (int j = 1; j < MAX_LAYERS - 1; j++) {
+                    if (j < Lm) {
+                        const int c4 = m.kr[j + 1] >> 2;
+                        const int rel = idx - m.w_begin4[j];
+                        const int row = (int)(((unsigned long long)(unsigned)rel * m.w_inv_c4[j]) >> 32);
+                        const int col = (rel - row * c4) * 4;
+                        const bool here = in && rel >= 0 && rel < m.kr[j] * c4;
+                        src = here ? p.W[j] + (size_t)row * m.ld[j + 1] + col : src;
+                        dst = here ? m.off_w[j] + row * m.lw[j] + col : dst;
+                    }
                 }
+                dsto[i] = dst;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dst >= 0) v[i] = *reinterpret_cast<const float4 *>(src);
             }
 #pragma unroll
-            for (int i = 0; i < MAXF; i++) {
-                if (dsto[i] >= 0) {
-                    float *dst = smem + dsto[i];
-                    dst[0] = v[i].x; dst[1] = v[i].y; dst[2] = v[i].z; dst[3] = v[i].w;
-                }
-            }
+            for (int i = 0; i < MAXF; i++)
+                if (dsto[i] >= 0) *reinterpret_cast<float4 *>(smem + dsto[i]) = v[i];
         }
     }
     __syncthreads();
@@ -203,21 +291,24 @@ __global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
     const bool live_row = row0 + rr < p.B;
 
     // ---- forward: layers 2 .. L-1 (SCE:172-194) ----
-    for (int l = 2; l <= Lm; l++) {
-        const int N = p.ld[l], G = (N + 63) / 64, gw = G * 64, KS = p.ks_fwd[l], k4n = p.kr[l - 1] / 4;
+#pragma unroll
+    for (int l = 2; l < MAX_LAYERS; l++) {
+        if (l > Lm) break;
+        const int N = m.ld[l], G = (m.kr[l] + 63) / 64, gw = G * 64, KS = m.ks_fwd[l], k4n = m.kr[l - 1] / 4;
         if (wave < G * KS) {
             const int g = wave % G, ks = wave / G;
-            rowblock_product<false>(smem + p.off_act[l - 1], p.ld[l - 1] + 4, smem + p.off_w[l - 1], N + 1,
+            rowblock_product<false>(smem + m.off_act[l - 1], m.ld[l - 1] + 4, smem + m.off_w[l - 1], m.lw[l - 1],
                                     ks * k4n / KS, (ks + 1) * k4n / KS, g * 64, 0,
-                                    smem + p.off_scratch + ks * 4 * gw, gw, lane);
+                                    smem + m.off_scratch + ks * 4 * gw, gw, lane);
         }
         __syncthreads();
         const bool last = (l == Lm);
-        float *img = smem + (last ? p.off_logits : p.off_act[l]);
+        float *img = smem + (last ? m.off_logits : m.off_act[l]);
         for (int n = rc; n < N; n += 256) {
             float v = 0.f;
-            for (int ks = 0; ks < KS; ks++) v += smem[p.off_scratch + (ks * 4 + rr) * gw + n];
-            const bool live = live_row && n < p.d[l];
+            if (n < m.kr[l])
+                for (int ks = 0; ks < KS; ks++) v += smem[m.off_scratch + (ks * 4 + rr) * gw + n];
+            const bool live = live_row && n < m.d[l];
             if (last) {
                 img[rr * (N + 4) + n] = live ? v : 0.f;
             } else {
@@ -233,13 +324,13 @@ __global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
 
     // ---- output layer: wave 0, one DPP row of 16 lanes per batch row ----
     if (wave == 0) {
-        const int N = p.ld[Lm], nt = p.d[Lm];
-        const int m = lane >> 4, c0 = lane & 15;
-        const int row = row0 + m;
+        const int N = m.ld[Lm], nt = m.d[Lm];
+        const int mr = lane >> 4, c0 = lane & 15;
+        const int row = row0 + mr;
         const bool lrow = row < p.B;
-        const float *z = smem + p.off_logits + m * (N + 4);
-        const float *y = smem + p.off_y + m * N;
-        float *dimg = smem + p.off_dl[Lm] + m * (N + 4);
+        const float *z = smem + m.off_logits + mr * (N + 4);
+        const float *y = smem + m.off_y + mr * N;
+        float *dimg = smem + m.off_dl[Lm] + mr * (N + 4);
         float mx = -INFINITY, lsum = 0.f;
         int best = -1;
         if (OUTK == 0) {
@@ -290,23 +381,26 @@ __global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
     GNN_STAMP4(3);
 
     // ---- backward data: delta_l = (delta_{l+1} . W_l^T) * f'(z_l), l = L-2 .. 1 (SCE:262-278) ----
-    for (int l = Lm - 1; l >= 1; l--) {
-        const int N = p.ld[l], NR = p.kr[l], G = (NR + 63) / 64, gw = G * 64, KS = p.ks_bwd[l];
-        const int k4n = p.kr[l + 1] / 4;
+#pragma unroll
+    for (int li = 0; li < MAX_LAYERS; li++) {
+        const int l = Lm - 1 - li;
+        if (l < 1) break;
+        const int N = m.ld[l], NR = m.kr[l], G = (NR + 63) / 64, gw = G * 64, KS = m.ks_bwd[l];
+        const int k4n = m.kr[l + 1] / 4;
         if (wave < G * KS) {
             const int g = wave % G, ks = wave / G;
-            rowblock_product<true>(smem + p.off_dl[l + 1], p.ld[l + 1] + 4, smem + p.off_w[l], p.ld[l + 1] + 1,
+            rowblock_product<true>(smem + m.off_dl[l + 1], m.ld[l + 1] + 4, smem + m.off_w[l], m.lw[l],
                                    ks * k4n / KS, (ks + 1) * k4n / KS, g * 64, NR,
-                                   smem + p.off_scratch + ks * 4 * gw, gw, lane);
+                                   smem + m.off_scratch + ks * 4 * gw, gw, lane);
         }
         __syncthreads();
-        const float *aimg = smem + p.off_act[l] + rr * (N + 4);
-        float *dimg = smem + p.off_dl[l] + rr * (N + 4);
+        const float *aimg = smem + m.off_act[l] + rr * (N + 4);
+        float *dimg = smem + m.off_dl[l] + rr * (N + 4);
         for (int n = rc; n < N; n += 256) {
             float v = 0.f;
             if (n < NR)
-                for (int ks = 0; ks < KS; ks++) v += smem[p.off_scratch + (ks * 4 + rr) * gw + n];
-            const bool live = live_row && n < p.d[l];
+                for (int ks = 0; ks < KS; ks++) v += smem[m.off_scratch + (ks * 4 + rr) * gw + n];
+            const bool live = live_row && n < m.d[l];
             const float dd = live ? v * act_prime_from_a(ACT, aimg[n]) : 0.f;
             if (l > 1) dimg[n] = dd;
             p.delta[l][(size_t)(row0 + rr) * N + n] = dd;
@@ -316,6 +410,18 @@ __global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
     }
     GNN_STAMP4(4);
     } // pass
+}
+
+template <class SH, int ACT, int OUTK, bool BACKWARD, bool STAMP = false>
+__global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
+    if constexpr (SH::is_static) {
+        // a LOCAL constexpr object: every member access with a compile-time index folds to an
+        // immediate (a namespace-scope constant would be loaded from memory)
+        constexpr Mid4Plan m = SH::make();
+        middle4_body<ACT, OUTK, BACKWARD, STAMP>(m, p);
+    } else {
+        middle4_body<ACT, OUTK, BACKWARD, STAMP>(p.plan, p);
+    }
 }
 
 } // namespace gnn

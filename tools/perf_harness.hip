@@ -7,6 +7,7 @@
 #include <vector>
 #include <algorithm>
 using namespace gnn;
+using SS = StaticShape<784, 300, 100, 10>;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 int main(int argc, char **argv) {
@@ -50,28 +51,17 @@ int main(int argc, char **argv) {
         gl.W = W + woff[l]; gl.V = V + woff[l]; gl.G = G + woff[l]; gl.M = ld[l]; gl.N = ld[l + 1]; gl.tiling = make_xcd_tiling((gl.M + 31) / 32, (gl.N + 31) / 32); gl.block_begin = tiles; tiles += gl.tiling.blocks(); }
     g.K = Bp; g.step_over_b = 0.0125f / B; g.momentum = 0.9f;
 
-    // middle4 plan (same arithmetic as plan_mid4 in gnn_mlp.hip)
-    Mid4Params m4{}; m4.L = L; size_t lds4 = 0;
+    // middle4 plan
+    Mid4Params m4{}; m4.plan = make_mid4_plan(dims, L); size_t lds4 = (size_t)m4.plan.lds_floats * 4;
     {
-        for (int l = 0; l < L; l++) { m4.d[l] = dims[l]; m4.ld[l] = ld[l]; m4.kr[l] = (dims[l] + 3) / 4 * 4; }
-        int o = 0; auto take = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
-        for (int l = 1; l < 3; l++) m4.off_w[l] = take(m4.kr[l] * (ld[l + 1] + 1));
-        for (int l = 1; l < 3; l++) m4.off_act[l] = take(4 * (ld[l] + 4));
-        m4.off_logits = take(4 * (ld[3] + 4));
-        for (int l = 2; l <= 3; l++) m4.off_dl[l] = take(4 * (ld[l] + 4));
-        m4.off_y = take(4 * ld[3]); m4.off_scratch = o;
-        m4.w_total4 = 0;
-        for (int l = 1; l < 3; l++) { int c4 = ld[l + 1] / 4; m4.w_begin4[l] = m4.w_total4; m4.w_total4 += m4.kr[l] * c4; m4.w_inv_c4[l] = (unsigned)(((1ull << 32) + c4 - 1) / c4); }
-        int budget = 160 * 1024 / 4 - 128 - o, scratch = 0;
-        for (int l = 2; l <= 3; l++) { int G = (ld[l] + 63) / 64, gw = G * 64, k4n = m4.kr[l - 1] / 4, ks = std::min(std::min(16 / G, k4n), budget / (4 * gw)); m4.ks_fwd[l] = ks; scratch = std::max(scratch, ks * 4 * gw); }
-        for (int l = 2; l >= 1; l--) { int G = (m4.kr[l] + 63) / 64, gw = G * 64, k4n = m4.kr[l + 1] / 4, ks = std::min(std::min(16 / G, k4n), budget / (4 * gw)); m4.ks_bwd[l] = ks; scratch = std::max(scratch, ks * 4 * gw); }
-        o += scratch + 128; lds4 = (size_t)o * 4;
-        printf("middle4: LDS %zu bytes, ks_fwd = %d %d, ks_bwd = %d %d\n", lds4, m4.ks_fwd[2], m4.ks_fwd[3], m4.ks_bwd[2], m4.ks_bwd[1]);
+        printf("middle4: LDS %zu bytes, ks_fwd = %d %d, ks_bwd = %d %d\n", lds4, m4.plan.ks_fwd[2], m4.plan.ks_fwd[3], m4.plan.ks_bwd[2], m4.plan.ks_bwd[1]);
         for (int l = 1; l < 3; l++) { m4.W[l] = W + woff[l]; m4.act[l] = act[l]; }
         for (int l = 1; l < L; l++) m4.delta[l] = delta[l];
         m4.Y = Y; m4.ldy = ld[3]; m4.loss = lossv; m4.label = labels; m4.B = B; m4.stamps = stamps;
-        CK(hipFuncSetAttribute((const void *)&middle4_kernel<0, 0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-        CK(hipFuncSetAttribute((const void *)&middle4_kernel<0, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        CK(hipFuncSetAttribute((const void *)&middle4_kernel<RuntimeShape, 0, 0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        CK(hipFuncSetAttribute((const void *)&middle4_kernel<RuntimeShape, 0, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        CK(hipFuncSetAttribute((const void *)&middle4_kernel<SS, 0, 0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        CK(hipFuncSetAttribute((const void *)&middle4_kernel<SS, 0, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     }
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -93,9 +83,11 @@ int main(int argc, char **argv) {
     time_it("fwd_first<16>", 500, k_first16);
     time_it("fwd_first<8,ACT=leaky>", 500, [&]() { hipLaunchKernelGGL((fwd_first_kernel<8, false, 0>), dim3(f.tiling.blocks()), dim3(512), 0, s, f); });
     time_it("middle<16>", 500, k_mid);
-    auto k_mid4 = [&]() { hipLaunchKernelGGL((middle4_kernel<0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
-    time_it("middle4", 500, k_mid4);
-    time_it("step with middle4", 500, [&]() { k_first(); k_mid4(); k_grad(); });
+    auto k_mid4r = [&]() { hipLaunchKernelGGL((middle4_kernel<RuntimeShape, 0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
+    auto k_mid4 = [&]() { hipLaunchKernelGGL((middle4_kernel<SS, 0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
+    time_it("middle4 runtime shape", 500, k_mid4r);
+    time_it("middle4 static shape", 500, k_mid4);
+    time_it("step with middle4 static", 500, [&]() { k_first(); k_mid4(); k_grad(); });
     time_it("grad_update<fused>", 500, k_grad);
     time_it("grad_update<store G>", 500, k_grad_nf);
     time_it("whole step (3 launches)", 500, [&]() { k_first(); k_mid(); k_grad(); });
@@ -144,12 +136,16 @@ int main(int argc, char **argv) {
         printf("\n");
     }
     {
-        hipLaunchKernelGGL((middle4_kernel<0, 0, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
+        for (int variant = 0; variant < 2; variant++) {
+        if (variant) hipLaunchKernelGGL((middle4_kernel<SS, 0, 0, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
+        else hipLaunchKernelGGL((middle4_kernel<RuntimeShape, 0, 0, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
         CK(hipStreamSynchronize(s));
+        printf("%s:\n", variant ? "STATIC shape" : "RUNTIME shape");
         std::vector<unsigned long long> hs(2 * 32 * 16);
         CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
-        for (int wg : {0, 9, 31, 32, 41, 63}) printf("middle4 stamps wg %d%s: load+stage=%llu fwdL2=%llu fwdL3=%llu output=%llu bwd2=%llu bwd1=%llu total=%llu\n", wg % 32, wg >= 32 ? " (2nd pass)" : "",
+        for (int wg : {0, 31, 32, 63}) printf("middle4 stamps wg %d%s: load+stage=%llu fwdL2=%llu fwdL3=%llu output=%llu bwd2=%llu bwd1=%llu total=%llu\n", wg % 32, wg >= 32 ? " (2nd pass)" : "",
             hs[wg*16+1]-hs[wg*16], hs[wg*16+6]-hs[wg*16+1], hs[wg*16+7]-hs[wg*16+6], hs[wg*16+3]-hs[wg*16+2], hs[wg*16+12]-hs[wg*16+3], hs[wg*16+11]-hs[wg*16+12], hs[wg*16+4]-hs[wg*16]);
+        }
     }
     k_mid_stamp(); CK(hipStreamSynchronize(s));
     std::vector<unsigned long long> hs(Bp / 16 * 16);
