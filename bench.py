@@ -135,17 +135,28 @@ def main():
         net.synchronize()
         fwd_us, fwd_n = net.timing_read(0)
         grad_us, grad_n = net.timing_read(1)
+        mid_us, mid_n = net.timing_read(3)
         net.timing_enable(False)
-        flop = 2.0 * BATCH * DIMS[0] * DIMS[1]  # 128 x 784 x 300 contraction, both kernels
-        # the first-layer weight-gradient GEMM (784x300, K = batch) and the first forward GEMM
-        # carry the same FLOPs; quote the slower one as the dominant kernel
-        name, us, cnt = (("grad_gemm0(784x300xB)", grad_us, grad_n) if grad_us >= fwd_us
-                         else ("fwd_gemm0(Bx784x300)", fwd_us, fwd_n))
+        P_all = sum(DIMS[l] * DIMS[l + 1] for l in range(len(DIMS) - 1))
+        P_mid = P_all - DIMS[0] * DIMS[1]
+        kernels = {  # algorithmic FLOPs per launch (2P fwd, 2(P - d0 d1) bwd-data, 2P grad, per sample)
+            "fwd_first(128x784x300)": (fwd_us, 2.0 * BATCH * DIMS[0] * DIMS[1]),
+            "middle(fwd L2.. + softmax + bwd-data)": (mid_us, 2.0 * BATCH * 2 * P_mid),
+            "grad_update(all layers, 784x300xB + ...)": (grad_us, 2.0 * BATCH * P_all),
+        }
+        step_us = dt / K * 1e6
+        # dominant kernel for the MFMA roofline: the one carrying the most FLOPs (the 784x300xB
+        # weight-gradient GEMMs + fused update); the per-kernel table shows the time shares
+        name = "grad_update(all layers, 784x300xB + ...)"
+        us, flop = kernels[name]
         ach = flop / (us * 1e-6) / 1e12 if us > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "avg_launch_us": round(us, 3), "launches": cnt,
-                    "other": {"fwd_gemm0_us": round(fwd_us, 3), "grad_gemm0_us": round(grad_us, 3)}}
+                    "avg_launch_us": round(us, 3), "launches": grad_n,
+                    "flop_per_launch": flop,
+                    "other": {k: {"avg_us": round(v[0], 3), "flop": v[1],
+                                  "tflops": round(v[1] / (v[0] * 1e-6) / 1e12, 3) if v[0] > 0 else None,
+                                  "share_of_step": round(v[0] / step_us, 3)} for k, v in kernels.items()}}
         if dist is None and not args.no_cpu_baseline:
             cpu = cpu_baseline()
 

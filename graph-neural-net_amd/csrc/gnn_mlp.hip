@@ -8,6 +8,7 @@
 #include "middle4_kernel.h"
 #include "kernels.h"
 
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -77,7 +78,7 @@ struct gnn_mlp {
     const void *mid4_fn[2] = {nullptr, nullptr}; // [backward]
 
     bool timing = false;
-    TimerClass timers[3];
+    TimerClass timers[4];
 };
 
 namespace {
@@ -117,11 +118,32 @@ struct ScopedTimer {
     }
 };
 
+// Launch with the dispatch's OWN begin/end timestamps (hipExtLaunchKernel start/stop events): the
+// elapsed time between them is the kernel's execution time, the same quantity rocprofv3's
+// kernel trace reports -- unlike events recorded around a launch, which add marker overhead.
+template <class K, class P> void launch_timed(gnn_mlp *h, int cls, K kernel, dim3 grid, dim3 block, size_t lds, const P &params) {
+    if (h->timing && cls >= 0) {
+        TimerClass &t = h->timers[cls];
+        if (t.used < 8192) {
+            if (t.used >= t.start.size()) {
+                hipEvent_t a = nullptr, b = nullptr;
+                if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { t.start.push_back(a); t.stop.push_back(b); }
+            }
+            if (t.used < t.start.size()) {
+                const size_t slot = t.used++;
+                hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, h->stream, t.start[slot], t.stop[slot], 0, params);
+                return;
+            }
+        }
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, h->stream, params);
+}
+
 // ---- GEMM dispatch ----------------------------------------------------------------------
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
-void launch_gemm_t(const GemmParams &p, hipStream_t s) {
+void launch_gemm_t(gnn_mlp *h, int cls, const GemmParams &p) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>), grid, dim3(256), 0, s, p);
+    launch_timed(h, cls, gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>, grid, dim3(256), 0, p);
 }
 
 // tile edge: keep >= ~256 workgroups in flight where the problem allows it (256 CUs)
@@ -133,11 +155,11 @@ int pick_tile(int M, int N) {
 }
 
 template <bool A_KC, bool B_KC, int EPI>
-void launch_gemm(const GemmParams &p, hipStream_t s) {
+void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
     switch (pick_tile(p.M, p.N)) {
-    case 128: launch_gemm_t<128, 128, A_KC, B_KC, EPI>(p, s); break;
-    case 64: launch_gemm_t<64, 64, A_KC, B_KC, EPI>(p, s); break;
-    default: launch_gemm_t<32, 32, A_KC, B_KC, EPI>(p, s); break;
+    case 128: launch_gemm_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;
+    case 64: launch_gemm_t<64, 64, A_KC, B_KC, EPI>(h, cls, p); break;
+    default: launch_gemm_t<32, 32, A_KC, B_KC, EPI>(h, cls, p); break;
     }
 }
 
@@ -155,13 +177,11 @@ void forward(gnn_mlp *h, const float *a0, int B) {
         p.act = h->inner_act;
         if (l < h->L - 1) {
             p.C = h->act[l]; p.ldc = h->ld[l];
-            if (l == 1) { ScopedTimer tm(h, GNN_K_FWD_GEMM0); launch_gemm<true, false, EPI_ACT>(p, h->stream); }
-            else launch_gemm<true, false, EPI_ACT>(p, h->stream);
+            launch_gemm<true, false, EPI_ACT>(h, l == 1 ? GNN_K_FWD_GEMM0 : -1, p);
             in = h->act[l];
         } else {
             p.C = h->logits; p.ldc = h->ld[l];
-            if (l == 1) { ScopedTimer tm(h, GNN_K_FWD_GEMM0); launch_gemm<true, false, EPI_STORE>(p, h->stream); }
-            else launch_gemm<true, false, EPI_STORE>(p, h->stream);
+            launch_gemm<true, false, EPI_STORE>(h, l == 1 ? GNN_K_FWD_GEMM0 : -1, p);
         }
     }
 }
@@ -196,7 +216,7 @@ void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_
             p.m_true = B; p.n_true = h->dims[l];
             p.aux = h->act[l]; p.ldaux = h->ld[l];
             p.act = h->inner_act;
-            launch_gemm<true, true, EPI_DACT>(p, h->stream);
+            launch_gemm<true, true, EPI_DACT>(h, -1, p);
         }
         GemmParams g{}; // G_l = A_l^T . delta_{l+1}
         g.A = (l == 0) ? a0 : h->act[l]; g.lda = h->ld[l];
@@ -204,17 +224,16 @@ void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_
         g.ldc = h->ld[l + 1];
         g.M = h->ld[l]; g.N = h->ld[l + 1]; g.K = B_pad;
         g.m_true = h->dims[l]; g.n_true = h->dims[l + 1];
-        ScopedTimer *tm = (l == 0) ? new ScopedTimer(h, GNN_K_GRAD_GEMM0) : nullptr;
+        const int cls = (l == 0) ? GNN_K_GRAD_GEMM0 : -1;
         if (fused_update) {
             g.C = nullptr;
             g.W = h->W + h->w_off[l]; g.V = h->V + h->w_off[l];
             g.step_over_b = step_over_b; g.momentum = momentum;
-            launch_gemm<false, false, EPI_SGD>(g, h->stream);
+            launch_gemm<false, false, EPI_SGD>(h, cls, g);
         } else {
             g.C = h->G + h->w_off[l];
-            launch_gemm<false, false, EPI_STORE>(g, h->stream);
+            launch_gemm<false, false, EPI_STORE>(h, cls, g);
         }
-        delete tm;
     }
 }
 
@@ -370,10 +389,7 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
     f.m_true = B; f.n_true = h->dims[1];
     f.act = h->inner_act; f.apply_act = 1;
     f.tiling = make_xcd_tiling(f.M / 16, f.N / 16);
-    {
-        ScopedTimer tm(h, GNN_K_FWD_GEMM0);
-        hipLaunchKernelGGL((fwd_first_kernel<FIRST_NW>), dim3(f.tiling.blocks()), dim3(FIRST_NW * 64), 0, h->stream, f);
-    }
+    launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW>, dim3(f.tiling.blocks()), dim3(FIRST_NW * 64), 0, f);
     if (h->mid4) {
         Mid4Params m4 = h->mid4p;
         m4.Y = y; m4.ldy = h->ld[h->L - 1];
@@ -383,6 +399,19 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
         m4.B = B;
         void *args[] = {&m4};
         // every padded row is processed: rows >= B become zeros
+        TimerClass &tc = h->timers[GNN_K_MIDDLE];
+        if (h->timing && tc.used < 8192) {
+            if (tc.used >= tc.start.size()) {
+                hipEvent_t a = nullptr, b = nullptr;
+                if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { tc.start.push_back(a); tc.stop.push_back(b); }
+            }
+            if (tc.used < tc.start.size()) {
+                const size_t slot = tc.used++;
+                (void)hipExtLaunchKernel(const_cast<void *>(h->mid4_fn[backward ? 1 : 0]), dim3(pad_up(B) / 4), dim3(1024), args,
+                                         h->mid4_lds_bytes, h->stream, tc.start[slot], tc.stop[slot], 0);
+                return;
+            }
+        }
         (void)hipLaunchKernel(h->mid4_fn[backward ? 1 : 0], dim3(pad_up(B) / 4), dim3(1024), args, h->mid4_lds_bytes, h->stream);
         return;
     }
@@ -392,7 +421,7 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
     m.loss = want_loss ? h->lossv : nullptr;
     m.label = want_label ? h->labels : nullptr;
     m.B = B; m.backward = backward ? 1 : 0;
-    hipLaunchKernelGGL((middle_kernel<MID_NW>), dim3(B_pad / 16), dim3(MID_NW * 64), h->mid_lds_bytes, h->stream, m);
+    launch_timed(h, GNN_K_MIDDLE, middle_kernel<MID_NW>, dim3(B_pad / 16), dim3(MID_NW * 64), h->mid_lds_bytes, m);
 }
 
 void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_over_b, float momentum) {
@@ -401,9 +430,8 @@ void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float
     for (int l = 0; l < g.n_layers; l++) g.layer[l].G = h->G + h->w_off[l];
     g.K = pad_up(B);
     g.step_over_b = step_over_b; g.momentum = momentum;
-    ScopedTimer tm(h, GNN_K_GRAD_GEMM0);
-    if (fused_update) hipLaunchKernelGGL((grad_update_kernel<true>), dim3(h->grad_tiles), dim3(256), 0, h->stream, g);
-    else hipLaunchKernelGGL((grad_update_kernel<false>), dim3(h->grad_tiles), dim3(256), 0, h->stream, g);
+    if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<true>, dim3(h->grad_tiles), dim3(256), 0, g);
+    else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<false>, dim3(h->grad_tiles), dim3(256), 0, g);
 }
 
 // the three shapes every entry point is made of
@@ -906,7 +934,7 @@ int gnn_mlp_timing_enable(gnn_mlp_t *h, int on) {
 
 int gnn_mlp_timing_read(gnn_mlp_t *h, int which, double *mean_us, int64_t *count) {
     TRY(check_handle(h));
-    if (which < 0 || which > 2 || !mean_us || !count) return fail(GNN_ERR_BAD_ARG, "bad timing query");
+    if (which < 0 || which > 3 || !mean_us || !count) return fail(GNN_ERR_BAD_ARG, "bad timing query");
     HIP_TRY(hipStreamSynchronize(h->stream));
     TimerClass &t = h->timers[which];
     double total = 0.0;

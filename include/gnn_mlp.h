@@ -167,12 +167,14 @@ int gnn_mlp_synchronize(gnn_mlp_t *h);
 
 /* ---- measurement support (bench.py) -------------------------------------------------------
  * Mean duration in microseconds of the kernel class `which` over the launches since the last
- * reset, measured with hipEvents on the handle's stream; timing must be enabled first
- * (it serialises nothing but adds two event records per launch). */
+ * reset.  Kernel classes are timed with the dispatch's own begin/end timestamps
+ * (hipExtLaunchKernel start/stop events on the handle's stream), i.e. the quantity rocprofv3's
+ * kernel trace reports; timing must be enabled first. */
 typedef enum {
     GNN_K_FWD_GEMM0 = 0,  /* first forward GEMM  (B x d_0 x d_1) */
     GNN_K_GRAD_GEMM0 = 1, /* first-layer weight-gradient GEMM (d_0 x d_1 x B) */
-    GNN_K_STEP = 2        /* one whole gradient step */
+    GNN_K_STEP = 2,       /* one whole gradient step (events recorded around the launches) */
+    GNN_K_MIDDLE = 3      /* fused path only: the per-row-block kernel between A_1 and delta_1 */
 } gnn_kernel_class;
 int gnn_mlp_timing_enable(gnn_mlp_t *h, int on);
 int gnn_mlp_timing_read(gnn_mlp_t *h, int which, double *mean_us, int64_t *count);
