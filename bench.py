@@ -27,6 +27,21 @@ STEP, MOMENTUM = 0.0125, 0.9  # MT:227-229
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
+def pmc_traffic(kernel_substring):
+    """L2<->fabric bytes per launch of a kernel from the committed rocprofv3 PMC passes
+    (profiles/r01/pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this very command,
+    FETCH_SIZE doubled as the gfx950 guide prescribes).  bench.py cannot collect PMCs itself."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            for name, d in json.load(f)["kernels"].items():
+                if kernel_substring in name:
+                    return round(d["traffic_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def synthetic(n, seed):
     """X ~ U[0,1) 784-dim, uniform one-hot labels; generated here, never shipped."""
     rng = np.random.default_rng(seed)
@@ -151,7 +166,8 @@ def main():
         us, flop = kernels[name]
         ach = flop / (us * 1e-6) / 1e12 if us > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": pmc_traffic("grad_update_kernel"),
                     "avg_launch_us": round(us, 3), "launches": grad_n,
                     "flop_per_launch": flop,
                     "other": {k: {"avg_us": round(v[0], 3), "flop": v[1],
