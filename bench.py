@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="data-parallel path: eager steps, no hipGraph replay")
     ap.add_argument("--dp-path", action="store_true",
                     help="run the data-parallel code path (compute -> all_reduce -> update) even at N=1")
     args = ap.parse_args()
@@ -123,11 +124,29 @@ def main():
         # data parallel (graph-neural-net_amd/data_parallel.py): kernels on torch's current stream,
         # gradient buffer owned by torch so that RCCL reduces it in place, one all-reduce per step
         from gnn_amd import data_parallel as dp
-        stepper = dp.DataParallelStep(dp.HipEngine(net, torch), dist)
+        side = torch.cuda.Stream()
+        stepper = dp.DataParallelStep(dp.HipEngine(net, torch, stream=side), dist, always_reduce=args.dp_path)
+        graphed = None
+        if not args.no_graph:
+            try:  # one pass over the 64 resident batches as ONE graph launch
+                graphed = dp.GraphedSteps(stepper, torch, side, [b * BATCH for b in range(n_batches)],
+                                          BATCH, STEP, MOMENTUM)
+            except Exception as e:  # capture of the collective not available: eager steps
+                if rank == 0:
+                    print("graph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
+                graphed = None
 
         def run(first_batch, n):
-            for s in range(n):
-                stepper.step(((first_batch + s) % n_batches) * BATCH, BATCH, STEP, MOMENTUM)
+            s = 0
+            with torch.cuda.stream(side):
+                while s < n:
+                    b = (first_batch + s) % n_batches
+                    if graphed is not None and b == 0 and n - s >= n_batches:
+                        graphed.replay()
+                        s += n_batches
+                    else:
+                        stepper.step(b * BATCH, BATCH, STEP, MOMENTUM)
+                        s += 1
 
     run(0, W)
     barrier()
@@ -192,6 +211,7 @@ def main():
             "config": {"workload": "784-300-100-10 SoftmaxCrossEntropyNeuralNet gradientStep, fp32, "
                                    "batch 128 per GPU (BASELINE configs[1])",
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
+                       "dp_mode": (None if dist is None else ("hipGraph replay of 64 steps" if graphed is not None else "eager")),
                        "step": STEP, "momentum": MOMENTUM, "inner_activation": "leaky_relu"},
             "roofline": roofline,
             "cpu_baseline": cpu,

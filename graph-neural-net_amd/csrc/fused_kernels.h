@@ -228,18 +228,29 @@ __global__ __launch_bounds__(256) void grad_update_kernel(GradParams p) {
         GNN_STAMP_AT(p.stamps, 1);
         const float *ap = &As[fq * LDS_LD + wm * 16 + fr];
         const float *dp = &Ds[fq * LDS_LD + wn * 16 + fr];
-        // 16 k (4 MFMAs) per trip, operands of the whole trip read before the first MFMA
-        for (int kk = 0; kk < kc; kk += 16) {
-            float a[4], d[4];
+        // 32 k (8 MFMAs) per trip, the trip's 16 LDS reads issued before its first MFMA; a full
+        // 128-row chunk is a compile-time trip count so the compiler overlaps consecutive trips
+        auto trip = [&](int kk) {
+            float a[8], d[8];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < 8; j++) {
                 a[j] = ap[(kk + 4 * j) * LDS_LD];
                 d[j] = dp[(kk + 4 * j) * LDS_LD];
             }
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], d[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], d[1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], d[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], d[3], acc1, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], d[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1], d[j + 1], acc1, 0, 0, 0);
+            }
+        };
+        if (kc == KC) {
+#pragma unroll
+            for (int kk = 0; kk < KC; kk += 32) trip(kk);
+        } else {
+            int kk = 0;
+            for (; kk + 32 <= kc; kk += 32) trip(kk);
+            for (; kk < kc; kk += 4) // kc is a multiple of 16
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * LDS_LD], dp[kk * LDS_LD], acc0, 0, 0, 0);
         }
     }
     const f32x4 acc = acc0 + acc1;

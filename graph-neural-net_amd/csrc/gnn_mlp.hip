@@ -917,6 +917,12 @@ int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentu
     return GNN_OK;
 }
 
+int gnn_mlp_advance_time(gnn_mlp_t *h, int steps) {
+    if (!h || h->time + steps < 0) return fail(GNN_ERR_BAD_ARG, "bad argument");
+    h->time += steps; // negative: steps that were only CAPTURED (enqueued into a graph, not run)
+    return GNN_OK;
+}
+
 int gnn_mlp_synchronize(gnn_mlp_t *h) {
     TRY(check_handle(h));
     HIP_TRY(hipStreamSynchronize(h->stream));

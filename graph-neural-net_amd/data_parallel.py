@@ -27,14 +27,16 @@ def shard_rows(n_rows, rank, world):
 
 class HipEngine:
     """Binds a torch-owned CUDA tensor as the net's gradient buffer and moves the net's kernels
-    onto torch's current stream, so that compute -> all_reduce -> update are stream-ordered with
-    no host synchronisation."""
+    onto a torch stream, so that compute -> all_reduce -> update are stream-ordered with no host
+    synchronisation."""
 
-    def __init__(self, net, torch_module):
+    def __init__(self, net, torch_module, stream=None):
         torch = torch_module
         self.net = net
+        self.torch = torch
         self.grad_tensor = torch.zeros(net.grad_elems, dtype=torch.float32, device="cuda")
-        net.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.stream = stream if stream is not None else torch.cuda.current_stream()
+        net.set_stream(self.stream.cuda_stream)
         net.bind_grad_buffer(self.grad_tensor.data_ptr(), self.grad_tensor.numel())
 
     def compute_gradient_range(self, first, B):
@@ -49,8 +51,9 @@ class HipEngine:
 
 
 class DataParallelStep:
-    def __init__(self, engine, dist_module=None, group=None):
+    def __init__(self, engine, dist_module=None, group=None, always_reduce=False):
         self.engine = engine
+        self.always_reduce = always_reduce  # run the collective even on one rank (plumbing tests)
         self.dist = dist_module
         self.group = group
         self.world = dist_module.get_world_size(group) if dist_module is not None else 1
@@ -60,7 +63,7 @@ class DataParallelStep:
         """One global gradientStep; every rank passes its own local rows."""
         self.engine.compute_gradient_range(first, B_local)
         B_global = B_local
-        if self.dist is not None and self.world > 1:
+        if self.dist is not None and (self.world > 1 or self.always_reduce):
             self.dist.all_reduce(self.engine.grad_tensor, op=self.dist.ReduceOp.SUM, group=self.group)
             B_global = B_local * self.world
         self.engine.apply_update(B_global, step, momentum)
@@ -76,3 +79,29 @@ class DataParallelStep:
         self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN, group=self.group)
         self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.group)
         return bool((lo == hi).all().item())
+
+
+class GraphedSteps:
+    """A fixed sequence of global gradientSteps captured ONCE into a HIP graph (stream capture of
+    the engine's kernels and the RCCL all-reduce on one side stream) and replayed with a single
+    launch: the per-step host work (three ABI calls and one collective launch) disappears, which
+    is what bounds a small-net step in eager mode.  Needs a HipEngine built on `stream`."""
+
+    def __init__(self, stepper, torch_module, stream, firsts, B_local, step, momentum):
+        torch = torch_module
+        self.stepper, self.torch, self.stream, self.n = stepper, torch, stream, len(firsts)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):   # one eager pass: lazy RCCL / allocator initialisation
+            for f in firsts:
+                stepper.step(f, B_local, step, momentum)
+        stream.synchronize()
+        with torch.cuda.graph(self.graph, stream=stream):
+            for f in firsts:
+                stepper.step(f, B_local, step, momentum)
+        stepper.engine.net.advance_time(-self.n)  # the capture pass enqueued, it did not run
+        self.eager_steps = self.n                 # steps really executed by the warm pass
+
+    def replay(self):
+        with self.torch.cuda.stream(self.stream):
+            self.graph.replay()
+        self.stepper.engine.net.advance_time(self.n)

@@ -249,6 +249,9 @@ class NeuralNet:
     def synchronize(self):
         _capi.check(self._lib.gnn_mlp_synchronize(self._h))
 
+    def advance_time(self, steps):
+        _capi.check(self._lib.gnn_mlp_advance_time(self._h, int(steps)))
+
     # -- measurement --------------------------------------------------------------------------
     def timing_enable(self, on=True):
         _capi.check(self._lib.gnn_mlp_timing_enable(self._h, int(bool(on))))

@@ -164,6 +164,11 @@ int gnn_mlp_compute_gradient(gnn_mlp_t *h, const double *X, const double *Y, int
 /* SCE:324-344 on the (all-reduced) gradient buffer with batchSize = B_global. */
 int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentum);
 int gnn_mlp_synchronize(gnn_mlp_t *h);
+/* A caller that captured steps into a hipGraph (stream capture on the stream given to
+ * gnn_mlp_set_stream) replays device work the host-side `time` counter (SCE:343) does not see;
+ * it reports the replayed steps here (and takes back, with a negative count, the steps that
+ * were only captured, not executed). */
+int gnn_mlp_advance_time(gnn_mlp_t *h, int steps);
 
 /* ---- measurement support (bench.py) -------------------------------------------------------
  * Mean duration in microseconds of the kernel class `which` over the launches since the last

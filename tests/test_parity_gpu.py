@@ -306,3 +306,31 @@ def test_full_size_configs_properties(gnn, dims, B):
     other.compute_gradient_range(0, B)
     other.apply_update(B, 0.0125, 0.9)
     assert np.abs(net.get_weights() - other.get_weights()).max() <= 1e-7
+
+
+def test_graph_replayed_steps_equal_eager(gnn):
+    """data_parallel.GraphedSteps: N steps captured once into a HIP graph and replayed == the same
+    N steps enqueued eagerly (single rank, no collective), and `time` counts executed steps."""
+    import torch
+    from gnn_amd import data_parallel as dp
+    dims, B, nb = [784, 300, 100, 10], 128, 6
+    X, Y = make_batch(dims, B * nb, seed=21)
+    firsts = [b * B for b in range(nb)]
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    a.upload_dataset(X, Y); b.upload_dataset(X, Y)
+    side = torch.cuda.Stream()
+    eng_a = dp.HipEngine(a, torch, stream=torch.cuda.Stream())
+    step_a = dp.DataParallelStep(eng_a)
+    for _ in range(3):
+        for f in firsts:
+            step_a.step(f, B, 0.0125, 0.9)
+    eng_b = dp.HipEngine(b, torch, stream=side)
+    step_b = dp.DataParallelStep(eng_b)
+    g = dp.GraphedSteps(step_b, torch, side, firsts, B, 0.0125, 0.9)   # runs the sequence once eagerly
+    assert b.time == nb
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert a.time == 3 * nb == b.time
+    wa, wb = a.get_weights(), b.get_weights()
+    assert np.array_equal(wa, wb)     # same kernels, same order: bitwise
