@@ -5,6 +5,7 @@
 #include "../../include/gnn_mlp.h"
 #include "java_random.h"
 #include "fused_kernels.h"
+#include "gemm_bf16.h"
 #include "middle4_kernel.h"
 #include "kernels.h"
 
@@ -143,7 +144,10 @@ template <class K, class P> void launch_timed(gnn_mlp *h, int cls, K kernel, dim
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
 void launch_gemm_t(gnn_mlp *h, int cls, const GemmParams &p) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-    launch_timed(h, cls, gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>, grid, dim3(256), 0, p);
+    if (h->dtype == GNN_DTYPE_BF16)
+        launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI>, grid, dim3(256), 0, p);
+    else
+        launch_timed(h, cls, gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>, grid, dim3(256), 0, p);
 }
 
 // tile edge: keep >= ~256 workgroups in flight where the problem allows it (256 CUs)
@@ -259,6 +263,7 @@ void plan_fused(gnn_mlp *h) {
     h->fused = false;
     const char *env = getenv("GNN_MLP_PATH");
     if (env && !strcmp(env, "generic")) return;
+    if (h->dtype != GNN_DTYPE_F32) return; // bf16 operands: generic per-layer GEMMs (gemm_bf16.h)
     const int L = h->L, Lm = L - 1;
     if (L < 3 || L > MAX_LAYERS) return;
     long mid_w = 0;
@@ -558,7 +563,7 @@ int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act,
     if (out_kind == GNN_OUT_ACT_LOSS && (last_act < 0 || last_act > GNN_ACT_IDENTITY))
         return fail(GNN_ERR_BAD_ARG, "bad last_act");
     if (out_kind == GNN_OUT_ACT_LOSS && loss != GNN_LOSS_HALF_SQUARED) return fail(GNN_ERR_BAD_ARG, "bad loss");
-    if (dtype != GNN_DTYPE_F32) return fail(GNN_ERR_UNSUPPORTED, "only GNN_DTYPE_F32 is built in this round");
+    if (dtype != GNN_DTYPE_F32 && dtype != GNN_DTYPE_BF16) return fail(GNN_ERR_BAD_ARG, "bad dtype");
     if (max_batch <= 0) return fail(GNN_ERR_BAD_ARG, "max_batch must be positive");
 
     int ndev = 0;

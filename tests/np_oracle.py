@@ -82,3 +82,51 @@ def gradient_step(w, v, dims, X, Y, step, momentum, inner, out_kind=0, last=1):
     g = gradient(split(w, dims), X, Y, inner, out_kind, last)
     adj = step * g / X.shape[0] + momentum * v        # SCE:333
     return w - adj, adj
+
+
+# ---- bf16-operand variant (GNN_DTYPE_BF16): GEMM operands rounded to bf16, everything else fp64 ----
+def bf16_round(x):
+    """fp64/fp32 -> fp32 -> bf16 (round to nearest even, what v_cvt_pk_bf16_f32 does) -> fp64."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64).reshape(np.shape(x))
+
+
+def forward_bf16(Ws, X, inner, out_kind=0, last=1):
+    """Activations / pre-activations as the bf16 GPU path forms them: every matrix product takes
+    bf16-rounded operands and accumulates exactly; activations are kept unrounded between layers
+    (they are fp32 in HBM and rounded when a tile is staged)."""
+    q = bf16_round
+    A = [act(inner, np.asarray(X, dtype=np.float64))]
+    Z = [np.asarray(X, dtype=np.float64)]
+    for l, W in enumerate(Ws):
+        z = q(A[-1]) @ q(W)
+        Z.append(z)
+        if l < len(Ws) - 1:
+            A.append(act(inner, z))
+    if out_kind == 0:
+        zz = Z[-1] - Z[-1].max(axis=1, keepdims=True)
+        e = np.exp(zz)
+        out = e / e.sum(axis=1, keepdims=True)
+    else:
+        out = act(last, Z[-1])
+    return Z, A, out
+
+
+def gradient_bf16(Ws, X, Y, inner, out_kind=0, last=1):
+    q = bf16_round
+    Z, A, out = forward_bf16(Ws, X, inner, out_kind, last)
+    L = len(Ws) + 1
+    D = out - Y if out_kind == 0 else (out - Y) * act_prime(last, Z[-1])
+    G = [None] * (L - 1)
+    for l in range(L - 2, -1, -1):
+        G[l] = q(A[l]).T @ q(D)
+        if l >= 1:
+            D = (q(D) @ q(Ws[l]).T) * act_prime(inner, Z[l])
+    return np.concatenate([g.ravel() for g in G])
+
+
+def gradient_step_bf16(w, v, dims, X, Y, step, momentum, inner, out_kind=0, last=1):
+    g = gradient_bf16(split(w, dims), X, Y, inner, out_kind, last)
+    adj = step * g / X.shape[0] + momentum * v
+    return w - adj, adj

@@ -1,0 +1,95 @@
+"""GNN_DTYPE_BF16 (bf16 GEMM operands, f32 accumulate, f32 master weights) through the C ABI.
+
+Two references:
+  * tests/np_oracle.py *_bf16: the fp64 matrix-form oracle with the SAME bf16 rounding applied to
+    every GEMM operand -- checks the kernels' arithmetic tightly (what differs is f32 accumulation
+    order and rare 1-ulp bf16 rounding flips of f32-vs-f64 activations);
+  * the plain fp64 oracle (the reference's arithmetic): loose, stated tolerance -- bf16 keeps 8
+    significant bits, logits of +-100 move by ~0.1-0.5, so class labels are compared only where the
+    fp64 top-2 margin exceeds that ("bf16 needs care").
+"""
+import numpy as np
+import pytest
+
+from tests import np_oracle
+
+pytestmark = pytest.mark.gpu
+LEAKY, SIGMOID = 0, 1
+
+
+def batch(dims, B, seed, keep=0.3):
+    rng = np.random.default_rng(seed)
+    X = rng.random((B, dims[0])) * (rng.random((B, dims[0])) < keep)
+    Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B)]
+    return X, Y
+
+
+@pytest.mark.parametrize("dims,B,inner", [([784, 100, 50, 10], 32, LEAKY), ([784, 300, 100, 10], 128, LEAKY),
+                                          ([784, 300, 100, 10], 48, SIGMOID), ([20, 17, 33, 7], 19, LEAKY)])
+def test_bf16_matches_bf16_oracle(gnn, dims, B, inner):
+    X, Y = batch(dims, B, 31)
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, dtype=gnn.DTYPE_BF16, max_batch=B)
+    w0 = net.get_weights()
+    Ws = np_oracle.split(w0, dims)
+    X32 = X.astype(np.float32).astype(np.float64)     # inputs are f32 in HBM
+    Z, A, out = np_oracle.forward_bf16(Ws, X32, inner)
+    p = net.propagate(X)
+    assert np.abs(p - out).max() <= 5e-3
+    zs = np.sort(Z[-1], axis=1)
+    margin = zs[:, -1] - zs[:, -2]
+    safe = margin > 2e-3 * np.abs(Z[-1]).max() + 1e-3
+    assert safe.mean() > 0.8
+    assert np.array_equal(net.argmax(X)[safe], Z[-1].argmax(axis=1)[safe])
+    g = net.calculateWeightGradient(X, Y)
+    gq = np_oracle.gradient_bf16(Ws, X32, Y, inner)
+    gf = np.concatenate([g[l].ravel() for l in sorted(g)])
+    off = 0
+    for l in range(len(dims) - 1):
+        n = dims[l] * dims[l + 1]
+        scale = np.abs(gq[off:off + n]).max()
+        assert np.abs(gf[off:off + n] - gq[off:off + n]).max() <= 4e-3 * scale + 1e-7, "layer %d" % l
+        off += n
+    w, v = w0.copy(), np.zeros_like(w0)
+    for s in range(3):
+        Xs, Ys = batch(dims, B, 40 + s)
+        net.gradientStep(Xs, 0.0125, 0.9, False, expected=Ys)
+        w, v = np_oracle.gradient_step_bf16(w, v, dims, Xs.astype(np.float32).astype(np.float64), Ys, 0.0125, 0.9, inner)
+    assert net.time == 3
+    assert np.abs(net.get_weights() - w).max() <= 2e-4
+
+
+def test_bf16_vs_fp64_reference_arithmetic(gnn, oracle_mod):
+    """Against the reference's own (fp64) arithmetic: stated bf16 tolerance."""
+    dims, B = [784, 300, 100, 10], 128
+    X, Y = batch(dims, B, 77)
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn.DTYPE_BF16, max_batch=B)
+    ref = oracle_mod.OracleNet(dims)
+    ref.set_alloc_per_sample(0)
+    logits = ref.logits(X)
+    zs = np.sort(logits, axis=1)
+    safe = (zs[:, -1] - zs[:, -2]) > 0.02 * np.abs(logits).max()    # bf16 logit error bound used here
+    assert safe.mean() > 0.5
+    assert np.array_equal(net.argmax(X)[safe], ref.argmax(X)[safe])
+    for s in range(3):
+        Xs, Ys = batch(dims, B, 80 + s)
+        net.gradientStep(Xs, 0.0125, 0.9, False, expected=Ys)
+        ref.gradient_step(Xs, Ys, 0.0125, 0.9)
+    d = np.abs(net.get_weights() - ref.get_weights())
+    assert d.max() <= 5e-3 and d.mean() <= 2e-4          # vs 2e-6 for the f32 path
+
+
+def test_bf16_full_size_properties(gnn):
+    """configs 4-like shape in bf16: gradient linearity over batch halves, sum p = 1."""
+    dims, B = [1024, 512, 512, 256], 256
+    rng = np.random.default_rng(5)
+    X = rng.random((B, dims[0])) * (rng.random((B, dims[0])) < 0.2)
+    Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B)]
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn.DTYPE_BF16, max_batch=B)
+    net.set_weights(net.get_weights() * 0.1)
+    p = net.propagate(X)
+    assert np.abs(p.sum(axis=1) - 1).max() < 1e-5
+    full = net.calculateWeightGradient(X, Y)
+    h1 = net.calculateWeightGradient(X[:B // 2], Y[:B // 2])
+    h2 = net.calculateWeightGradient(X[B // 2:], Y[B // 2:])
+    for l in full:
+        assert np.abs(full[l] - (h1[l] + h2[l])).max() <= 1e-5 * np.abs(full[l]).max() + 1e-9

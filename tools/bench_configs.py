@@ -15,14 +15,16 @@ CONFIGS = {
 }
 
 def main():
-    which = sys.argv[1:] or ["1", "2", "5", "4"]
+    args = sys.argv[1:]
+    dtype = gnn_amd.DTYPE_BF16 if "bf16" in args else gnn_amd.DTYPE_F32
+    which = [a for a in args if a != "bf16"] or ["1", "2", "5", "4"]
     for key in which:
         dims, B = CONFIGS[key]
         rng = np.random.default_rng(0)
         nb = 8
         X = rng.random((B * nb, dims[0])) * (rng.random((B * nb, dims[0])) < 0.19)
         Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B * nb)]
-        net = gnn_amd.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+        net = gnn_amd.SoftmaxCrossEntropyNeuralNet(dims, dtype=dtype, max_batch=B)
         if dims[0] > 1000:
             net.set_weights(net.get_weights() * 0.05)
         net.upload_dataset(X, Y)
@@ -33,7 +35,7 @@ def main():
         dt = time.perf_counter() - t0
         P = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1))
         flop = (6 * P - 2 * dims[0] * dims[1]) * B
-        print("config %s %s B=%d: %.2f us/step, %.3g samples/s, %.2f TFLOP/s (%.1f%% of 157.3 fp32 MFMA)" % (
+        print(("bf16 " if dtype else "f32  ") + "config %s %s B=%d: %.2f us/step, %.3g samples/s, %.2f TFLOP/s (%.1f%% of 157.3 fp32 MFMA)" % (
             key, "-".join(map(str, dims)), B, dt / steps * 1e6, steps * B / dt, flop / (dt / steps) / 1e12,
             100 * flop / (dt / steps) / 157.3e12), flush=True)
         net.close()
