@@ -13,3 +13,4 @@ from .neural_net import (  # noqa: F401
     ACT_IDENTITY, ACT_LEAKY_RELU, ACT_RELU, ACT_SIGMOID, ACT_TANH, DTYPE_BF16, DTYPE_F32,
     LOSS_HALF_SQUARED, OUT_ACT_LOSS, OUT_SOFTMAX_CE, GeneralNeuralNet, NeuralNet,
     SoftmaxCrossEntropyNeuralNet)
+from .trainer import NeuralNetTrainer, Sampler, accuracy, read_idx_images, read_idx_labels  # noqa: F401

@@ -876,6 +876,97 @@ int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels) {
     return read_labels(h, B, labels);
 }
 
+// ---- trainer-side sampling (NNT:143-168) ----------------------------------------------------
+} // extern "C"
+
+struct gnn_sampler {
+    int32_t master = 0, remaining = 0;
+    std::vector<int32_t> fen; // Fenwick tree over "row still in dataSampler": the r-th remaining
+                              // row in master order is what ArrayList.get(r) returns after removals
+    JavaRandom rnd{1};
+    int log2n = 0;
+    void refill() { // refillSampler NNT:164-168
+        fen.assign((size_t)master + 1, 0);
+        for (int32_t i = 1; i <= master; i++) {
+            fen[i] += 1;
+            const int32_t j = i + (i & -i);
+            if (j <= master) fen[j] += fen[i];
+        }
+        remaining = master;
+    }
+    int32_t take(int32_t r) { // remove and return the r-th (0-based) remaining row
+        int32_t pos = 0, k = r + 1;
+        for (int32_t pw = 1 << log2n; pw > 0; pw >>= 1)
+            if (pos + pw <= master && fen[pos + pw] < k) { pos += pw; k -= fen[pos]; }
+        for (int32_t i = pos + 1; i <= master; i += i & -i) fen[i] -= 1;
+        remaining--;
+        return pos; // 0-based row
+    }
+};
+
+extern "C" {
+
+int gnn_sampler_create(int32_t master_size, int64_t seed, gnn_sampler_t **out) {
+    if (!out || master_size <= 0) return fail(GNN_ERR_BAD_ARG, "bad sampler arguments");
+    gnn_sampler *s = new gnn_sampler();
+    s->master = master_size;
+    s->rnd.set_seed(seed);
+    while ((1 << (s->log2n + 1)) <= master_size) s->log2n++;
+    s->refill();
+    *out = s;
+    return GNN_OK;
+}
+
+int gnn_sampler_destroy(gnn_sampler_t *s) { delete s; return GNN_OK; }
+
+int gnn_sampler_sample(gnn_sampler_t *s, int batch, int32_t *out_idx, int *n_out) {
+    if (!s || !out_idx || !n_out || batch <= 0) return fail(GNN_ERR_BAD_ARG, "bad sampler arguments");
+    int n = 0;
+    for (int i = 0; i < batch; i++) {
+        if (s->remaining == 0) s->refill();                       // NNT:149-151
+        const int32_t r = s->rnd.next_int(s->remaining);           // NNT:152
+        const int32_t row = s->take(r);                            // NNT:153-154
+        bool dup = false;                                          // HashMap.put, NNT:155
+        for (int k = 0; k < n; k++) if (out_idx[k] == row) { dup = true; break; }
+        if (!dup) out_idx[n++] = row;
+    }
+    *n_out = n;
+    return GNN_OK;
+}
+
+static int step_on_device_indices(gnn_mlp *h, const int32_t *d_idx, int B, double step, double momentum) {
+    const int B_pad = pad_up(B), Lm = h->L - 1;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * h->ld[0] / 4)), dim3(256), 0, h->stream,
+                       h->DX, h->ld[0], d_idx, B, B_pad, h->act[0]);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * h->ld[Lm] / 4)), dim3(256), 0, h->stream,
+                       h->DY, h->ld[Lm], d_idx, B, B_pad, h->ybuf);
+    return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum);
+}
+
+int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step, double momentum,
+                          int noise) {
+    TRY(check_handle(h));
+    if (!s) return fail(GNN_ERR_BAD_ARG, "null sampler");
+    TRY(check_step_args(h, batch, step, noise));
+    if (!h->DX) return fail(GNN_ERR_STATE, "no dataset uploaded");
+    if (iterations <= 0) return fail(GNN_ERR_BAD_ARG, "iterations must be positive (NNT:62)");
+    if (s->master != h->dataset_n) return fail(GNN_ERR_BAD_ARG, "sampler size differs from the dataset");
+    if (batch >= s->master) return fail(GNN_ERR_BAD_ARG, "batchSize must be below the data size (NNT:63)");
+    std::vector<int32_t> idx((size_t)iterations * batch);
+    std::vector<int> cnt((size_t)iterations);
+    for (int i = 0; i < iterations; i++) TRY(gnn_sampler_sample(s, batch, idx.data() + (size_t)i * batch, &cnt[i]));
+    int32_t *d_idx = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_idx, idx.size() * sizeof(int32_t)));
+    hipError_t e = hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+    int rc = GNN_OK;
+    if (e != hipSuccess) rc = fail(GNN_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    for (int i = 0; i < iterations && rc == GNN_OK; i++)
+        rc = step_on_device_indices(h, d_idx + (size_t)i * batch, cnt[i], step, momentum);
+    (void)hipStreamSynchronize(h->stream); // idx (host) and d_idx are released below
+    (void)hipFree(d_idx);
+    return rc;
+}
+
 // ---- data-parallel hooks --------------------------------------------------------------------
 int gnn_mlp_grad_device_ptr(gnn_mlp_t *h, void **dev_ptr) {
     if (!h || !dev_ptr) return fail(GNN_ERR_BAD_ARG, "null argument");

@@ -146,6 +146,24 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
 int gnn_mlp_loss_range(gnn_mlp_t *h, int64_t first, int B, double *loss_per_sample);
 int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels);
 
+/* ---- the trainer's sampling loop (NeuralNetTrainer.java) ------------------------------------ */
+
+/* Epoch sampler without replacement, NNT:28-43 + NNT:143-168: java.util.Random(seed) (the
+ * reference uses 1, NNT:42), nextInt(remaining) picks the r-th REMAINING sample in master order
+ * (ArrayList.get(r) + remove(r), NNT:152-154), the list refills when empty -- also in the middle
+ * of a batch (NNT:149-151), in which case a sample drawn twice collapses in the reference's
+ * HashMap (NNT:155) and the batch is shorter than requested.  Master order here is
+ * dataset row order (the reference's is HashMap iteration order, i.e. unspecified). */
+typedef struct gnn_sampler gnn_sampler_t;
+int gnn_sampler_create(int32_t master_size, int64_t seed, gnn_sampler_t **out);
+int gnn_sampler_destroy(gnn_sampler_t *s);
+/* One sample(batchSize) call: writes the DISTINCT rows in first-draw order, *n_out of them. */
+int gnn_sampler_sample(gnn_sampler_t *s, int batch, int32_t *out_idx, int *n_out);
+/* The loop NNT:82-85 / NNT:88-90: `iterations` times { sample(batch); gradientStep }. All draws
+ * are made up front and uploaded once; the steps are then enqueued with no host->device copy. */
+int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step,
+                          double momentum, int noise);
+
 /* ---- data-parallel hooks (one process per GPU; the exchange is the caller's collective) -- */
 
 /* The reference sums per-sample gradients at SCE:305-322 and divides by batch.size() at

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "gnn_mlp.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(gnn_mlp_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(gnn_(?:mlp|sampler)_\w+)\s*\(", text)))
 
 
 def test_header_declares_the_interface():

@@ -1,0 +1,67 @@
+"""NeuralNetTrainer mirror and MNIST data handling (N2) on the GPU."""
+import io
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sampler_matches_oracle_restatement(gnn, oracle_mod):
+    """product sampler (Fenwick tree) == oracle sampler (ArrayList-style memmove), incl. the
+    mid-batch refill and the duplicate collapse (NNT:143-168)."""
+    for master, batch, draws in ((60000, 128, 40), (10, 4, 12), (37, 16, 20), (1000, 999, 5)):
+        a, b = gnn.Sampler(master), oracle_mod.Sampler(master)
+        for _ in range(draws):
+            x, y = a.sample(batch), b.sample(batch)
+            assert np.array_equal(x, y)
+    assert gnn.Sampler(60000).sample(5)[0] == 8985      # Random(1).nextInt(60000)
+
+
+def test_train_equals_stepwise_and_oracle(gnn, oracle_mod):
+    dims, N, B, iters = [784, 100, 50, 10], 300, 32, 25      # crosses an epoch boundary (300 / 32)
+    rng = np.random.default_rng(2)
+    pix = rng.integers(0, 256, (N, 784), dtype=np.uint8)
+    pix[rng.random((N, 784)) < 0.8] = 0
+    lab = rng.integers(0, 10, N, dtype=np.uint8)
+    X, Y = pix / 255.0, np.eye(10)[lab]
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    ta = gnn.NeuralNetTrainer(pix, lab, a, raw_u8=True)
+    tb = gnn.NeuralNetTrainer(X, Y, b)
+    ta.train(iters, 0.01, B, 0.9, False)                      # gnn_mlp_train_sampled
+    obs = io.StringIO()
+    tb.train(iters, 0.01, B, 0.9, False, observer=obs)        # per-iteration path with validation
+    assert a.time == iters == b.time
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    lines = obs.getvalue().strip().split("\n")
+    assert len(lines) == iters and lines[0].startswith("0,") and lines[-1].startswith("%d," % (iters - 1))
+    # the same draws through the oracle
+    ref = oracle_mod.OracleNet(dims)
+    ref.set_alloc_per_sample(0)
+    smp = oracle_mod.Sampler(N)
+    for _ in range(iters):
+        idx = smp.sample(B)
+        ref.gradient_step(X[idx], Y[idx], 0.01, 0.9)
+    assert np.abs(a.get_weights() - ref.get_weights()).max() <= 2e-6 * iters
+    vs = N // 100 + 1
+    v_ref = ref.calculate_loss(X[:vs], Y[:vs]).mean()
+    assert abs(tb.validate(vs) - v_ref) <= 2e-4 * abs(v_ref) + 2e-4
+    assert float(lines[-1].split(",")[1]) == pytest.approx(round(v_ref, 2), abs=0.011)
+    acc = gnn.accuracy(a, lab)
+    acc_ref = float((ref.argmax(X) == lab).mean())
+    assert abs(acc - acc_ref) <= 2.0 / N
+
+
+def test_idx_reader(gnn, tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (7, 28, 28), dtype=np.uint8)
+    lab = rng.integers(0, 10, 7, dtype=np.uint8)
+    (tmp_path / "img").write_bytes(struct.pack(">iiii", 2051, 7, 28, 28) + img.tobytes())
+    (tmp_path / "lab").write_bytes(struct.pack(">ii", 2049, 7) + lab.tobytes())
+    assert np.array_equal(gnn.read_idx_images(tmp_path / "img"), img.reshape(7, 784))
+    assert np.array_equal(gnn.read_idx_labels(tmp_path / "lab"), lab)
+    (tmp_path / "bad").write_bytes(struct.pack(">ii", 2051, 7) + lab.tobytes())
+    with pytest.raises(ValueError):
+        gnn.read_idx_labels(tmp_path / "bad")
