@@ -354,8 +354,20 @@ const void *mid4_function(const gnn_mlp *h, bool bwd) {
         if (shape_matches<ShapeMnistA>(h)) return mid4_fn_sh<ShapeMnistA, 0>(h->inner_act, bwd);
         if (shape_matches<ShapeMnistB>(h)) return mid4_fn_sh<ShapeMnistB, 0>(h->inner_act, bwd);
     }
-    return h->out_kind == GNN_OUT_SOFTMAX_CE ? mid4_fn_sh<RuntimeShape, 0>(h->inner_act, bwd)
-                                             : mid4_fn_sh<RuntimeShape, 1>(h->inner_act, bwd);
+    // runtime extents: layer count templated (3..6, else generic), activation read from the arguments
+#define GNN_M4R(NL) (h->out_kind == GNN_OUT_SOFTMAX_CE                                                                    \
+        ? (bwd ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, 0, true>)                              \
+               : reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, 0, false>))                            \
+        : (bwd ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, 1, true>)                              \
+               : reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, 1, false>)))
+    switch (h->L) {
+    case 3: return GNN_M4R(3);
+    case 4: return GNN_M4R(4);
+    case 5: return GNN_M4R(5);
+    case 6: return GNN_M4R(6);
+    default: return GNN_M4R(0);
+    }
+#undef GNN_M4R
 }
 
 void plan_mid4(gnn_mlp *h) {
@@ -371,6 +383,7 @@ void plan_mid4(gnn_mlp *h) {
     for (int l = 1; l < Lm; l++) { m.W[l] = h->W + h->w_off[l]; m.act[l] = h->act[l]; }
     for (int l = 1; l <= Lm; l++) m.delta[l] = h->delta[l];
     m.last_act = h->last_act;
+    m.inner_act = h->inner_act;
     for (int bwd = 0; bwd < 2; bwd++) {
         h->mid4_fn[bwd] = mid4_function(h, bwd != 0);
         if (hipFuncSetAttribute(h->mid4_fn[bwd], hipFuncAttributeMaxDynamicSharedMemorySize,

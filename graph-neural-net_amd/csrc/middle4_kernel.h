@@ -113,15 +113,19 @@ struct Mid4Params {
     const float *Y; int ldy;
     float *prob; float *loss; int32_t *label;
     int B;
-    int last_act;
+    int inner_act, last_act;     // inner_act is read only by kernels built with ACT = -1
     unsigned long long *stamps;  // STAMP builds only
 };
 
-struct RuntimeShape {
+// NL > 0: the layer COUNT is a compile-time constant (extents stay kernel arguments), so the
+// per-layer loops unroll with constant trip counts and constant kernarg offsets; NL = 0: any L.
+template <int NL> struct RuntimeShape {
     static constexpr bool is_static = false;
+    static constexpr int kL = NL;
 };
 template <int... DIMS> struct StaticShape {
     static constexpr bool is_static = true;
+    static constexpr int kL = (int)sizeof...(DIMS);
     static constexpr int kDims[sizeof...(DIMS)] = {DIMS...};
     __host__ __device__ static constexpr Mid4Plan make() {
         constexpr int dims[sizeof...(DIMS)] = {DIMS...};
@@ -214,14 +218,15 @@ __device__ __forceinline__ void rowblock_product(const float *A_img, int lda, co
     for (int i = 0; i < 4; i++) partial[i * gw + n0 + lane] = acc[i];
 }
 
-template <int ACT, int OUTK, bool BACKWARD, bool STAMP>
+template <int NL, int ACT_T, int OUTK, bool BACKWARD, bool STAMP>
 __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
+    const int ACT = (ACT_T >= 0) ? ACT_T : p.inner_act;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT_ = 1024;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // provably wave-uniform: scalar branches
     const int row0 = blockIdx.x * 4;
-    const int L = m.L, Lm = L - 1;
+    const int L = (NL > 0) ? NL : m.L, Lm = L - 1;
     // STAMP builds run the body twice and stamp the second (warm) pass into the next record
     for (int pass = 0; pass < (STAMP ? 2 : 1); pass++) {
     if (STAMP && pass == 1) { __syncthreads(); p.stamps += 16 * gridDim.x; }
@@ -418,9 +423,9 @@ __global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
         // a LOCAL constexpr object: every member access with a compile-time index folds to an
         // immediate (a namespace-scope constant would be loaded from memory)
         constexpr Mid4Plan m = SH::make();
-        middle4_body<ACT, OUTK, BACKWARD, STAMP>(m, p);
+        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP>(m, p);
     } else {
-        middle4_body<ACT, OUTK, BACKWARD, STAMP>(p.plan, p);
+        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP>(p.plan, p);
     }
 }
 

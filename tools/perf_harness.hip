@@ -57,9 +57,9 @@ int main(int argc, char **argv) {
         printf("middle4: LDS %zu bytes, ks_fwd = %d %d, ks_bwd = %d %d\n", lds4, m4.plan.ks_fwd[2], m4.plan.ks_fwd[3], m4.plan.ks_bwd[2], m4.plan.ks_bwd[1]);
         for (int l = 1; l < 3; l++) { m4.W[l] = W + woff[l]; m4.act[l] = act[l]; }
         for (int l = 1; l < L; l++) m4.delta[l] = delta[l];
-        m4.Y = Y; m4.ldy = ld[3]; m4.loss = lossv; m4.label = labels; m4.B = B; m4.stamps = stamps;
-        CK(hipFuncSetAttribute((const void *)&middle4_kernel<RuntimeShape, 0, 0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-        CK(hipFuncSetAttribute((const void *)&middle4_kernel<RuntimeShape, 0, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        m4.Y = Y; m4.ldy = ld[3]; m4.loss = lossv; m4.label = labels; m4.B = B; m4.stamps = stamps; m4.inner_act = 0;
+        CK(hipFuncSetAttribute((const void *)&middle4_kernel<RuntimeShape<4>, 0, 0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        CK(hipFuncSetAttribute((const void *)&middle4_kernel<RuntimeShape<4>, 0, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
         CK(hipFuncSetAttribute((const void *)&middle4_kernel<SS, 0, 0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
         CK(hipFuncSetAttribute((const void *)&middle4_kernel<SS, 0, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     }
@@ -83,7 +83,7 @@ int main(int argc, char **argv) {
     time_it("fwd_first<16>", 500, k_first16);
     time_it("fwd_first<8,ACT=leaky>", 500, [&]() { hipLaunchKernelGGL((fwd_first_kernel<8, false, 0>), dim3(f.tiling.blocks()), dim3(512), 0, s, f); });
     time_it("middle<16>", 500, k_mid);
-    auto k_mid4r = [&]() { hipLaunchKernelGGL((middle4_kernel<RuntimeShape, 0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
+    auto k_mid4r = [&]() { hipLaunchKernelGGL((middle4_kernel<RuntimeShape<4>, 0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
     auto k_mid4 = [&]() { hipLaunchKernelGGL((middle4_kernel<SS, 0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
     time_it("middle4 runtime shape", 500, k_mid4r);
     time_it("middle4 static shape", 500, k_mid4);
@@ -138,7 +138,7 @@ int main(int argc, char **argv) {
     {
         for (int variant = 0; variant < 2; variant++) {
         if (variant) hipLaunchKernelGGL((middle4_kernel<SS, 0, 0, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
-        else hipLaunchKernelGGL((middle4_kernel<RuntimeShape, 0, 0, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
+        else hipLaunchKernelGGL((middle4_kernel<RuntimeShape<4>, 0, 0, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
         CK(hipStreamSynchronize(s));
         printf("%s:\n", variant ? "STATIC shape" : "RUNTIME shape");
         std::vector<unsigned long long> hs(2 * 32 * 16);
