@@ -38,6 +38,8 @@ SYMBOLS = [
     ("gnn_mlp_set_weights", C.c_int, [_H, _dp]),
     ("gnn_mlp_get_momentum", C.c_int, [_H, _dp]),
     ("gnn_mlp_set_momentum", C.c_int, [_H, _dp]),
+    ("gnn_mlp_save_checkpoint", C.c_int, [_H, C.c_char_p]),
+    ("gnn_mlp_load_checkpoint", C.c_int, [_H, C.c_char_p]),
     ("gnn_mlp_upload_dataset", C.c_int, [_H, _dp, _dp, C.c_int64]),
     ("gnn_mlp_upload_dataset_u8", C.c_int, [_H, _u8, _u8, C.c_int64]),
     ("gnn_mlp_dataset_size", C.c_int64, [_H]),

@@ -760,6 +760,45 @@ int gnn_mlp_set_weights(gnn_mlp_t *h, const double *flat) { TRY(check_handle(h))
 int gnn_mlp_get_momentum(gnn_mlp_t *h, double *flat) { TRY(check_handle(h)); return get_flat(h, h->V, flat); }
 int gnn_mlp_set_momentum(gnn_mlp_t *h, const double *flat) { TRY(check_handle(h)); return set_flat(h, h->V, flat); }
 
+// ---- checkpoint -----------------------------------------------------------------------------
+int gnn_mlp_save_checkpoint(gnn_mlp_t *h, const char *path) {
+    TRY(check_handle(h));
+    if (!path) return fail(GNN_ERR_BAD_ARG, "null path");
+    std::vector<double> w((size_t)h->n_params), v((size_t)h->n_params);
+    TRY(get_flat(h, h->W, w.data()));
+    TRY(get_flat(h, h->V, v.data()));
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(GNN_ERR_BAD_ARG, std::string("cannot open ") + path);
+    const char magic[8] = {'G', 'N', 'N', 'M', 'L', 'P', '1', 0};
+    const int32_t L = h->L, tm = h->time;
+    bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(&L, 4, 1, f) == 1;
+    for (int l = 0; ok && l < L; l++) { const int32_t d = h->dims[l]; ok = fwrite(&d, 4, 1, f) == 1; }
+    ok = ok && fwrite(&tm, 4, 1, f) == 1 && fwrite(w.data(), 8, w.size(), f) == w.size() &&
+         fwrite(v.data(), 8, v.size(), f) == v.size();
+    ok = (fclose(f) == 0) && ok;
+    return ok ? GNN_OK : fail(GNN_ERR_BAD_ARG, std::string("short write to ") + path);
+}
+
+int gnn_mlp_load_checkpoint(gnn_mlp_t *h, const char *path) {
+    TRY(check_handle(h));
+    if (!path) return fail(GNN_ERR_BAD_ARG, "null path");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(GNN_ERR_BAD_ARG, std::string("cannot open ") + path);
+    char magic[8];
+    int32_t L = 0, tm = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, "GNNMLP1", 8) && fread(&L, 4, 1, f) == 1 && L == h->L;
+    for (int l = 0; ok && l < L; l++) { int32_t d = 0; ok = fread(&d, 4, 1, f) == 1 && d == h->dims[l]; }
+    std::vector<double> w((size_t)h->n_params), v((size_t)h->n_params);
+    ok = ok && fread(&tm, 4, 1, f) == 1 && tm >= 0 && fread(w.data(), 8, w.size(), f) == w.size() &&
+         fread(v.data(), 8, v.size(), f) == v.size();
+    fclose(f);
+    if (!ok) return fail(GNN_ERR_BAD_ARG, std::string(path) + ": not a checkpoint of this net");
+    TRY(set_flat(h, h->W, w.data()));
+    TRY(set_flat(h, h->V, v.data()));
+    h->time = tm;
+    return GNN_OK;
+}
+
 // ---- dataset ------------------------------------------------------------------------------
 static int alloc_dataset(gnn_mlp *h, int64_t N) {
     HIP_TRY(hipStreamSynchronize(h->stream)); // nothing in flight may still read the old dataset

@@ -173,6 +173,12 @@ class NeuralNet:
     def time(self):
         return self._lib.gnn_mlp_time(self._h)
 
+    def save_checkpoint(self, path):
+        _capi.check(self._lib.gnn_mlp_save_checkpoint(self._h, str(path).encode()))
+
+    def load_checkpoint(self, path):
+        _capi.check(self._lib.gnn_mlp_load_checkpoint(self._h, str(path).encode()))
+
     # -- device-resident data (the trainer's side of the boundary, NNT:28-43,143-168) ---------
     def upload_dataset(self, X, Y):
         X = _f64(X, self.layer_dims[0])

@@ -120,6 +120,13 @@ int gnn_mlp_set_weights(gnn_mlp_t *h, const double *flat);
 int gnn_mlp_get_momentum(gnn_mlp_t *h, double *flat);
 int gnn_mlp_set_momentum(gnn_mlp_t *h, const double *flat);
 
+/* Checkpoint (the reference has no persistence at all: a trained net is lost at JVM exit,
+ * SURVEY 5).  File = "GNNMLP1\0", int32 L, int32 dims[L], int32 time, fp64 weights[P],
+ * fp64 momentum[P], little endian, flat layer-major row-major [in][out] like get_weights.
+ * Loading requires identical dims. */
+int gnn_mlp_save_checkpoint(gnn_mlp_t *h, const char *path);
+int gnn_mlp_load_checkpoint(gnn_mlp_t *h, const char *path);
+
 /* ---- device-resident training data (the caller of the path: NNT:28-43, NNT:143-168) ------ */
 
 /* Copies N samples to HBM once (fp64 -> compute dtype, inner activation applied to the input

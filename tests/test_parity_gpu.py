@@ -334,3 +334,40 @@ def test_graph_replayed_steps_equal_eager(gnn):
     assert a.time == 3 * nb == b.time
     wa, wb = a.get_weights(), b.get_weights()
     assert np.array_equal(wa, wb)     # same kernels, same order: bitwise
+
+
+@pytest.mark.parametrize("dims,B,inner", [
+    ([784, 512, 256, 10], 64, LEAKY),          # middle weights exceed LDS -> 16-row middle_kernel
+    ([100, 64, 48, 32, 10], 40, SIGMOID),      # L = 5, middle4 with runtime shape
+    ([60, 50, 40, 30, 20, 10], 33, TANH),      # L = 6
+    ([784, 300, 100, 10], 1000, LEAKY),        # large batch (250 row blocks)
+    ([300, 10], 50, LEAKY),                    # L = 2: generic path, no hidden layer
+    ([784, 1200, 10], 24, RELU),               # one wide hidden layer (19 column groups backward)
+])
+def test_more_shapes_take_every_path(gnn, oracle_mod, dims, B, inner):
+    rng = np.random.default_rng(13)
+    X = rng.random((B, dims[0])) * (rng.random((B, dims[0])) < 0.3)
+    Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B)]
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    ref = oracle_mod.OracleNet(dims, inner_act=inner)
+    ref.set_alloc_per_sample(0)
+    Bo = min(B, 48)                            # the serial oracle is slow: compare on the first rows
+    assert np.abs(net.propagate(X)[:Bo] - ref.propagate(X[:Bo])).max() <= P_ATOL
+    g = net.calculateWeightGradient(X[:Bo], Y[:Bo])
+    gr = sum(ref.calculate_weight_gradient(X[b], Y[b]) for b in range(Bo))
+    off = 0
+    for l in range(len(dims) - 1):
+        n = dims[l] * dims[l + 1]
+        grl = gr[off:off + n].reshape(dims[l], dims[l + 1])
+        off += n
+        assert np.abs(g[l] - grl).max() <= 3e-5 * np.abs(grl).max() + 1e-9, "layer %d" % l
+    for s in range(2):
+        net.gradientStep(X[:Bo], 0.0125, 0.9, False, expected=Y[:Bo])
+        ref.gradient_step(X[:Bo], Y[:Bo], 0.0125, 0.9)
+    assert np.abs(net.get_weights() - ref.get_weights()).max() <= 3 * W_ATOL
+    if B > Bo:                                 # full batch: linearity of the gradient over halves
+        full = net.calculateWeightGradient(X, Y)
+        h1 = net.calculateWeightGradient(X[:B // 2], Y[:B // 2])
+        h2 = net.calculateWeightGradient(X[B // 2:], Y[B // 2:])
+        for l in full:
+            assert np.abs(full[l] - (h1[l] + h2[l])).max() <= 2e-5 * np.abs(full[l]).max() + 1e-9

@@ -65,3 +65,23 @@ def test_idx_reader(gnn, tmp_path):
     (tmp_path / "bad").write_bytes(struct.pack(">ii", 2051, 7) + lab.tobytes())
     with pytest.raises(ValueError):
         gnn.read_idx_labels(tmp_path / "bad")
+
+
+def test_checkpoint_round_trip(gnn, tmp_path):
+    dims, B = [784, 100, 50, 10], 32
+    rng = np.random.default_rng(4)
+    X = rng.random((B * 4, 784)); Y = np.eye(10)[rng.integers(0, 10, B * 4)]
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    a.upload_dataset(X, Y)
+    a.train_range(0, B, 3, 0.0125, 0.9)
+    a.save_checkpoint(tmp_path / "ck.bin")
+    a.train_range(0, B, 2, 0.0125, 0.9)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b.load_checkpoint(tmp_path / "ck.bin")
+    assert b.time == 3
+    b.upload_dataset(X, Y)
+    b.train_range(0, B, 2, 0.0125, 0.9)        # resume: momentum restored too
+    assert np.array_equal(a.get_weights(), b.get_weights()) and a.time == b.time == 5
+    c = gnn.SoftmaxCrossEntropyNeuralNet([784, 100, 40, 10], max_batch=B)
+    with pytest.raises(gnn.GnnError):
+        c.load_checkpoint(tmp_path / "ck.bin")
