@@ -78,6 +78,12 @@ struct gnn_mlp {
     size_t mid4_lds_bytes = 0;
     const void *mid4_fn[2] = {nullptr, nullptr}; // [backward]
 
+    // train_range graph: one pass over the dataset's batches captured once, replayed many times
+    hipGraphExec_t tr_exec = nullptr;
+    hipGraph_t tr_graph = nullptr;
+    int64_t tr_first_batch = -1; int tr_B = 0; int64_t tr_nb = 0; double tr_step = 0, tr_mom = 0;
+    const float *tr_dx = nullptr;
+
     bool timing = false;
     TimerClass timers[4];
 };
@@ -661,6 +667,8 @@ int gnn_mlp_destroy(gnn_mlp_t *h) {
     for (float *p : h->delta) fr(p);
     fr(h->logits); fr(h->prob); fr(h->ybuf); fr(h->lossv); fr(h->labels); fr(h->idxbuf);
     fr(h->stage_x); fr(h->stage_y); fr(h->stage_out); fr(h->DX); fr(h->DY);
+    if (h->tr_exec) (void)hipGraphExecDestroy(h->tr_exec);
+    if (h->tr_graph) (void)hipGraphDestroy(h->tr_graph);
     for (TimerClass &t : h->timers) {
         for (hipEvent_t e : t.start) (void)hipEventDestroy(e);
         for (hipEvent_t e : t.stop) (void)hipEventDestroy(e);
@@ -879,7 +887,51 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
     if (n_steps <= 0) return fail(GNN_ERR_BAD_ARG, "n_steps must be positive (NNT:62)");
     const int64_t nb = h->dataset_n / B;
     if (nb <= 0 || first < 0 || first % B != 0) return fail(GNN_ERR_BAD_ARG, "first must be a multiple of B inside the dataset");
-    for (int s = 0; s < n_steps; s++) {
+    int s = 0;
+    // hipGraph replay: when the request covers whole passes over the nb batches, one pass
+    // (nb steps, 3 launches each on the fused path) is captured ONCE from this very stream and
+    // replayed with a single launch per pass; the remainder runs eagerly.  Off while per-kernel
+    // timing is on (timed launches carry events) and on a caller-provided stream (the caller
+    // may be capturing itself); GNN_MLP_GRAPH=0 disables it.
+    const char *genv = getenv("GNN_MLP_GRAPH");
+    const bool want_graph = !(genv && !strcmp(genv, "0")) && !h->timing && h->stream == h->own_stream &&
+                            nb >= 2 && nb <= 1024 && n_steps >= 2 * nb;
+    if (want_graph) {
+        const int64_t fb = (first / B) % nb;
+        const bool hit = h->tr_exec && h->tr_first_batch == fb && h->tr_B == B && h->tr_nb == nb &&
+                         h->tr_step == step && h->tr_mom == momentum && h->tr_dx == h->DX;
+        if (!hit) {
+            if (h->tr_exec) { (void)hipGraphExecDestroy(h->tr_exec); h->tr_exec = nullptr; }
+            if (h->tr_graph) { (void)hipGraphDestroy(h->tr_graph); h->tr_graph = nullptr; }
+            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int t0 = h->time;
+                int rc = GNN_OK;
+                for (int64_t b = 0; b < nb && rc == GNN_OK; b++) {
+                    const int64_t row0 = ((fb + b) % nb) * B;
+                    rc = step_on_rows(h, h->DX + (size_t)row0 * h->ld[0], h->DY + (size_t)row0 * h->ld[h->L - 1], B, step, momentum);
+                }
+                h->time = t0; // captured, not executed
+                hipGraph_t g = nullptr;
+                const hipError_t e = hipStreamEndCapture(h->stream, &g);
+                if (rc == GNN_OK && e == hipSuccess && g && hipGraphInstantiate(&h->tr_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                    h->tr_graph = g;
+                    h->tr_first_batch = fb; h->tr_B = B; h->tr_nb = nb; h->tr_step = step; h->tr_mom = momentum; h->tr_dx = h->DX;
+                } else {
+                    if (g) (void)hipGraphDestroy(g);
+                    h->tr_exec = nullptr;
+                    (void)hipGetLastError();
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        while (h->tr_exec && n_steps - s >= nb) {
+            HIP_TRY(hipGraphLaunch(h->tr_exec, h->stream));
+            h->time += (int)nb;
+            s += (int)nb;
+        }
+    }
+    for (; s < n_steps; s++) {
         const int64_t row0 = ((first / B + s) % nb) * B;
         TRY(step_on_rows(h, h->DX + (size_t)row0 * h->ld[0], h->DY + (size_t)row0 * h->ld[h->L - 1], B, step,
                          momentum));

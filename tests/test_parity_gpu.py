@@ -371,3 +371,23 @@ def test_more_shapes_take_every_path(gnn, oracle_mod, dims, B, inner):
         h2 = net.calculateWeightGradient(X[B // 2:], Y[B // 2:])
         for l in full:
             assert np.abs(full[l] - (h1[l] + h2[l])).max() <= 2e-5 * np.abs(full[l]).max() + 1e-9
+
+
+def test_train_range_graph_replay_equals_stepwise(gnn):
+    """gnn_mlp_train_range replays a captured hipGraph of one pass when the request covers whole
+    passes: same kernels, same order -> bitwise equal to step-by-step calls; `time` is right."""
+    dims, B, nb = [784, 300, 100, 10], 128, 5
+    X, Y = make_batch(dims, B * nb, seed=33)
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    a.upload_dataset(X, Y); b.upload_dataset(X, Y)
+    n = 3 * nb + 2
+    a.train_range(B, B, n, 0.0125, 0.9)          # starts at batch 1: 3 replayed passes + 2 eager steps
+    a.train_range(B, B, 2 * nb, 0.0125, 0.9)     # cached graph reused? (first batch differs -> recapture)
+    for s in range(n):
+        b.gradient_step_range(((1 + s) % nb) * B, B, 0.0125, 0.9)
+    for s in range(2 * nb):
+        b.gradient_step_range(((1 + s) % nb) * B, B, 0.0125, 0.9)
+    assert a.time == b.time == n + 2 * nb
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    assert np.array_equal(a.get_momentum(), b.get_momentum())

@@ -17,6 +17,13 @@ __global__ void probe(unsigned long long *out, int iters, float *sink) {
 }
 __global__ void empty_kernel(float *p) { if (p && threadIdx.x == 9999) *p = 1.f; }
 
+__global__ void pingpong(const float4 *in, float4 *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float4 v = in[i];
+    v.x += 1.f; v.y += 1.f; v.z += 1.f; v.w += 1.f;
+    out[i] = v;
+}
+
 int main() {
     unsigned long long *d; float *sink;
     hipMalloc(&d, 16); hipMalloc(&sink, 4);
@@ -43,6 +50,31 @@ int main() {
         hipEventRecord(b, s); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         printf("1000 empty kernels grid %4d: %.2f us each\n", g, ms);
+    }
+    {   // dependent chain of minimal load -> store kernels: the floor of one "real" kernel
+        float4 *pa, *pb;
+        hipMalloc(&pa, 1 << 22); hipMalloc(&pb, 1 << 22);
+        hipMemset(pa, 0, 1 << 22); hipMemset(pb, 0, 1 << 22);
+        for (int g : {8, 64, 256, 1024}) {
+            for (int i = 0; i < 50; i++) { hipLaunchKernelGGL(pingpong, dim3(g), dim3(256), 0, s, pa, pb); hipLaunchKernelGGL(pingpong, dim3(g), dim3(256), 0, s, pb, pa); }
+            hipEventRecord(a, s);
+            for (int i = 0; i < 500; i++) { hipLaunchKernelGGL(pingpong, dim3(g), dim3(256), 0, s, pa, pb); hipLaunchKernelGGL(pingpong, dim3(g), dim3(256), 0, s, pb, pa); }
+            hipEventRecord(b, s); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            printf("dependent load->store kernels, grid %4d x 256 threads (16 B per thread): %.2f us each\n", g, ms);
+        }
+        // the same chain captured in a graph (no host launch limit)
+        hipGraph_t graph; hipGraphExec_t exec;
+        hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        for (int i = 0; i < 100; i++) { hipLaunchKernelGGL(pingpong, dim3(256), dim3(256), 0, s, pa, pb); hipLaunchKernelGGL(pingpong, dim3(256), dim3(256), 0, s, pb, pa); }
+        hipStreamEndCapture(s, &graph);
+        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphLaunch(exec, s); hipStreamSynchronize(s);
+        hipEventRecord(a, s);
+        for (int i = 0; i < 10; i++) hipGraphLaunch(exec, s);
+        hipEventRecord(b, s); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("same chain, hipGraph (200 kernels per graph): %.2f us each\n", ms * 1000.f / 2000.f);
     }
     return 0;
 }

@@ -82,6 +82,24 @@ int main() {
         }
         printf("%-52s grid %3d: median %6llu cycles (%.1f B/clk), max(last rep) %6llu\n", name, grid, best_med, n4 * 16.0 / best_med, mx);
     };
+    {   // does L2 survive a kernel boundary for data nobody rewrote?
+        std::vector<unsigned long long> h(32);
+        hipLaunchKernelGGL(touch, dim3(256), dim3(256), 0, s, w, n4, 1.f);
+        for (int rep = 0; rep < 4; rep++) {
+            hipLaunchKernelGGL((stream<1024, 0>), dim3(32), dim3(1024), 0, s, w, n4, 0, 0, out, sink);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h.data(), out, 32 * 8, hipMemcpyDeviceToHost);
+            std::sort(h.begin(), h.end());
+            printf("re-read without rewrite, launch %d: median %llu cycles, min %llu\n", rep, h[16], h[0]);
+        }
+        for (int rep = 0; rep < 3; rep++) {   // back-to-back without host sync in between
+            hipLaunchKernelGGL((stream<1024, 0>), dim3(32), dim3(1024), 0, s, w, n4, 0, 0, out, sink);
+        }
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), out, 32 * 8, hipMemcpyDeviceToHost);
+        std::sort(h.begin(), h.end());
+        printf("re-read, 3 launches back to back, last: median %llu cycles, min %llu\n", h[16], h[0]);
+    }
     for (int grid : {32}) {
         run("shared, to LDS [row][113] 4 x b32 writes", grid, 0, 0, 4);
         run("shared, to LDS [row][113] 4 x b32 rotated comps", grid, 0, 0, 5);
