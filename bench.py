@@ -25,6 +25,7 @@ DIMS = [784, 300, 100, 10]
 BATCH = 128
 STEP, MOMENTUM = 0.0125, 0.9  # MT:227-229
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
 def pmc_traffic(kernel_substring):
@@ -173,24 +174,37 @@ def main():
         net.timing_enable(False)
         P_all = sum(DIMS[l] * DIMS[l + 1] for l in range(len(DIMS) - 1))
         P_mid = P_all - DIMS[0] * DIMS[1]
-        kernels = {  # algorithmic FLOPs per launch (2P fwd, 2(P - d0 d1) bwd-data, 2P grad, per sample)
-            "fwd_first(128x784x300)": (fwd_us, 2.0 * BATCH * DIMS[0] * DIMS[1]),
-            "middle(fwd L2.. + softmax + bwd-data)": (mid_us, 2.0 * BATCH * 2 * P_mid),
-            "grad_update(all layers, 784x300xB + ...)": (grad_us, 2.0 * BATCH * P_all),
+        e4 = 4  # bytes per element (f32)
+        # algorithmic work per launch (SURVEY 8d accounting):
+        #   fwd_first : 2*B*d0*d1 FLOP; reads A_0 (B*d0) + W_0 (d0*d1), writes A_1 (B*d1)
+        #   middle    : 2*B*2*(P - d0 d1) FLOP; reads W_1.. once per use (fwd + bwd), A_1, Y; writes A_2.., delta_1..
+        #   grad      : 2*B*P FLOP; reads A_l, delta_{l+1} for every layer and W, V (2P); writes W, V (2P)
+        hidden = sum(DIMS[1:-1])
+        kernels = {
+            "fwd_first(128x784x300)": (fwd_us, 2.0 * BATCH * DIMS[0] * DIMS[1],
+                                       e4 * (BATCH * DIMS[0] + DIMS[0] * DIMS[1] + BATCH * DIMS[1])),
+            "middle(fwd L2.. + softmax + bwd-data)": (mid_us, 2.0 * BATCH * 2 * P_mid,
+                                                      e4 * (2 * P_mid + BATCH * (DIMS[1] + 2 * DIMS[-1] + 2 * sum(DIMS[1:])))),
+            "grad_update(all layers, 784x300xB + ...)": (grad_us, 2.0 * BATCH * P_all,
+                                                         e4 * (4 * P_all + BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:])))),
         }
         step_us = dt / K * 1e6
-        # dominant kernel for the MFMA roofline: the one carrying the most FLOPs (the 784x300xB
-        # weight-gradient GEMMs + fused update); the per-kernel table shows the time shares
+        # roofline kernel: the one that moves the most bytes and FLOPs -- every layer's G = A^T.delta
+        # with the momentum update fused.  Its arithmetic intensity (13 FLOP/B) is below the f32
+        # ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B), so the bound that applies is HBM.
         name = "grad_update(all layers, 784x300xB + ...)"
-        us, flop = kernels[name]
-        ach = flop / (us * 1e-6) / 1e12 if us > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+        us, flop, nbytes = kernels[name]
+        ach = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": pmc_traffic("grad_update_kernel"),
                     "avg_launch_us": round(us, 3), "launches": grad_n,
-                    "flop_per_launch": flop,
-                    "other": {k: {"avg_us": round(v[0], 3), "flop": v[1],
+                    "algorithmic_bytes_per_launch": nbytes, "flop_per_launch": flop,
+                    "arithmetic_intensity_flop_per_byte": round(flop / nbytes, 2),
+                    "mfma_frac": round(flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if us > 0 else None,
+                    "other": {k: {"avg_us": round(v[0], 3), "flop": v[1], "algorithmic_bytes": v[2],
                                   "tflops": round(v[1] / (v[0] * 1e-6) / 1e12, 3) if v[0] > 0 else None,
+                                  "gbs": round(v[2] / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else None,
                                   "share_of_step": round(v[0] / step_us, 3)} for k, v in kernels.items()}}
         if dist is None and not args.no_cpu_baseline:
             cpu = cpu_baseline()
