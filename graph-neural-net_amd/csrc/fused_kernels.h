@@ -411,9 +411,11 @@ __global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
             const float *y = p.Y ? p.Y + (size_t)row * p.ldy : nullptr;
             float mx = -INFINITY, l = 0.f;
             int best = -1;
+            bool has_nan = false; // MT:166-168 NaN rule, see output_layer_kernel
             if (p.out_kind == 0) {
                 for (int c = lane; c < nt; c += 64) {
                     const float v = z[c];
+                    has_nan |= (v != v);
                     if (v >= mx) { mx = v; best = c; }
                 }
 #pragma unroll
@@ -448,6 +450,7 @@ __global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
                     if (p.backward) p.delta[Lm][(size_t)row * N + c] = d;
                     if (live) {
                         l += 0.5f * df * df;
+                        if (c == 0) has_nan = (a != a);
                         if (a >= mx) { mx = a; best = c; }
                     }
                 }
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
                     if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
                 }
             }
+            if (__any(has_nan)) best = 0;
             l = wave_sum(l);
             if (lane == 0) {
                 if (p.loss) p.loss[row] = live_row ? l : 0.f;

@@ -828,15 +828,22 @@ int gnn_mlp_upload_dataset(gnn_mlp_t *h, const double *X, const double *Y, int64
     double *sx = nullptr, *sy = nullptr;
     HIP_TRY(hipMalloc((void **)&sx, sizeof(double) * chunk * d0));
     HIP_TRY(hipMalloc((void **)&sy, sizeof(double) * chunk * dl));
-    for (int64_t r0 = 0; r0 < N; r0 += chunk) {
+    hipError_t err = hipSuccess;
+    for (int64_t r0 = 0; r0 < N && err == hipSuccess; r0 += chunk) {
         const int64_t n = (N - r0 < chunk) ? N - r0 : chunk;
-        (void)hipMemcpyAsync(sx, X + r0 * d0, sizeof(double) * n * d0, hipMemcpyHostToDevice, h->stream);
-        (void)hipMemcpyAsync(sy, Y + r0 * dl, sizeof(double) * n * dl, hipMemcpyHostToDevice, h->stream);
+        err = hipMemcpyAsync(sx, X + r0 * d0, sizeof(double) * n * d0, hipMemcpyHostToDevice, h->stream);
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(sy, Y + r0 * dl, sizeof(double) * n * dl, hipMemcpyHostToDevice, h->stream);
+        if (err != hipSuccess) break;
         hipLaunchKernelGGL(convert_rows_f64_kernel, dim3(grid_for(n * h->ld[0])), dim3(256), 0, h->stream, sx, d0,
                            h->DX + (size_t)r0 * h->ld[0], h->ld[0], n, n, h->inner_act, 1);
         hipLaunchKernelGGL(convert_rows_f64_kernel, dim3(grid_for(n * h->ld[h->L - 1])), dim3(256), 0, h->stream, sy,
                            dl, h->DY + (size_t)r0 * h->ld[h->L - 1], h->ld[h->L - 1], n, n, 0, 0);
-        (void)hipStreamSynchronize(h->stream);
+        err = hipStreamSynchronize(h->stream); // the staging buffers are reused by the next chunk
+    }
+    if (err != hipSuccess) {
+        (void)hipFree(sx); (void)hipFree(sy);
+        return fail(GNN_ERR_HIP, std::string("dataset upload: ") + hipGetErrorString(err));
     }
     (void)hipFree(sx); (void)hipFree(sy);
     HIP_TRY(hipGetLastError());

@@ -258,11 +258,16 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
     const float *z = p.Z + (size_t)row * p.ldz;
     const float *y = p.Y ? p.Y + (size_t)row * p.ldy : nullptr;
 
+    // NaN rule of MT:166-168: the scan starts with actual = 0 and `x >= NaN` is false, so a NaN
+    // at index 0 is sticky (label 0) while a NaN elsewhere is never selected.  With softmax any
+    // NaN logit makes EVERY probability NaN, i.e. label 0.
+    bool has_nan = false;
     if (p.out_kind == 0) {
         float mx = -INFINITY;
         int best = -1;
         for (int c = lane; c < p.n_true; c += 64) {
             const float v = z[c];
+            has_nan |= (v != v);
             if (v >= mx) { mx = v; best = c; } // ascending c within a lane: `>=` keeps the highest
         }
         // wave argmax: larger value wins, equal values -> higher index (MT:166-168)
@@ -287,6 +292,7 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
             if (live && yy != 0.f) l += yy * (lse - z[c]); // -y ln p
         }
         l = wave_sum(l);
+        if (__any(has_nan)) best = 0;
         if (lane == 0) {
             if (p.loss) p.loss[row] = live_row ? l : 0.f;
             if (p.label) p.label[row] = live_row ? best : -1;
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
             if (p.delta) p.delta[(size_t)row * p.ldd + c] = live ? d * act_prime_from_a(p.last_act, a) : 0.f;
             if (live) {
                 l += 0.5f * d * d;
+                if (c == 0) has_nan = (a != a); // element-wise output: only a NaN at index 0 is sticky
                 if (a >= mx) { mx = a; best = c; }
             }
         }
@@ -315,6 +322,7 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
             if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
         }
         l = wave_sum(l);
+        if (__any(has_nan)) best = 0;
         if (lane == 0) {
             if (p.loss) p.loss[row] = live_row ? l : 0.f;
             if (p.label) p.label[row] = live_row ? best : -1;

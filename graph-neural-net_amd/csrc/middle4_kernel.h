@@ -336,11 +336,12 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
         const float *z = smem + m.off_logits + mr * (N + 4);
         const float *y = smem + m.off_y + mr * N;
         float *dimg = smem + m.off_dl[Lm] + mr * (N + 4);
-        float mx = -INFINITY, lsum = 0.f;
+        float mx = -INFINITY, lsum = 0.f, nan_flag = 0.f; // MT:166-168 NaN rule, see output_layer_kernel
         int best = -1;
         if (OUTK == 0) {
             for (int c = c0; c < nt; c += 16) {
                 const float v = z[c];
+                if (v != v) nan_flag = 1.f;
                 if (v >= mx) { mx = v; best = c; }
             }
             row16_argmax(mx, best);
@@ -370,11 +371,13 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                 if (BACKWARD) p.delta[Lm][(size_t)row * N + c] = dd;
                 if (live) {
                     lsum += 0.5f * df * df;
+                    if (c == 0 && a != a) nan_flag = 1.f;
                     if (a >= mx) { mx = a; best = c; }
                 }
             }
             row16_argmax(mx, best);
         }
+        if (row16_sum(nan_flag) > 0.f) best = 0;
         lsum = row16_sum(lsum);
         if (c0 == 0) {
             if (p.loss) p.loss[row] = lrow ? lsum : 0.f;

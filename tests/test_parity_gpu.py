@@ -391,3 +391,17 @@ def test_train_range_graph_replay_equals_stepwise(gnn):
     assert a.time == b.time == n + 2 * nb
     assert np.array_equal(a.get_weights(), b.get_weights())
     assert np.array_equal(a.get_momentum(), b.get_momentum())
+
+
+def test_argmax_nan_rule(gnn, oracle_mod):
+    """MT:166-168 with NaNs: the scan starts at actual = 0 and `x >= NaN` is false, so a NaN at
+    index 0 is sticky.  A NaN weight makes every softmax probability NaN -> label 0."""
+    for dims in ([8, 6, 5], [784, 100, 50, 10], [40, 10]):
+        net = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=4)
+        ref = oracle_mod.OracleNet(dims)
+        w = net.get_weights()
+        w[-1] = np.nan                         # last weight of the last layer: poisons one logit
+        net.set_weights(w); ref.set_weights(w)
+        X = np.random.default_rng(1).random((4, dims[0])) + 0.1
+        assert np.array_equal(ref.argmax(X), np.zeros(4, dtype=np.int32))
+        assert np.array_equal(net.argmax(X), np.zeros(4, dtype=np.int32))
