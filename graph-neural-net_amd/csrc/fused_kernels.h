@@ -43,7 +43,7 @@ struct XcdTiling {
         return tm < tiles_m && tn < tiles_n && (j / rn) < rm;
     }
 };
-inline XcdTiling make_xcd_tiling(int tiles_m, int tiles_n) {
+__host__ inline XcdTiling make_xcd_tiling(int tiles_m, int tiles_n) {
     XcdTiling best{};
     long best_cost = -1;
     for (int xn = 1; xn <= 8; xn *= 2) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
             const bool live_row = row < p.B;
             const float *z = smem + p.off_logits + m * ldsn;
             const float *y = p.Y ? p.Y + (size_t)row * p.ldy : nullptr;
-            float mx = -INFINITY, l = 0.f;
+            float mx = -__builtin_inff(), l = 0.f;
             int best = -1;
             bool has_nan = false; // MT:166-168 NaN rule, see output_layer_kernel
             if (p.out_kind == 0) {

@@ -4,6 +4,7 @@
 // their epilogue (single GPU) or written to the flat gradient buffer (data parallel).
 #include "../../include/gnn_mlp.h"
 #include "java_random.h"
+#include "jit.h"
 #include "fused_kernels.h"
 #include "gemm_bf16.h"
 #include "middle4_kernel.h"
@@ -77,6 +78,10 @@ struct gnn_mlp {
     Mid4Params mid4p{};
     size_t mid4_lds_bytes = 0;
     const void *mid4_fn[2] = {nullptr, nullptr}; // [backward]
+    hipFunction_t mid4_jit[2] = {nullptr, nullptr}; // run-time instantiation (jit.h), preferred when set
+    int specialization = 0;   // 0 runtime-shape kernels, 1 prebuilt static shape, 2 run-time instantiation
+    bool jit_tried = false;
+    int steps_seen = 0;       // gradient computations so far: the 16th triggers the specialisation
 
     // train_range graph: one pass over the dataset's batches captured once, replayed many times
     hipGraphExec_t tr_exec = nullptr;
@@ -390,6 +395,12 @@ void plan_mid4(gnn_mlp *h) {
     for (int l = 1; l <= Lm; l++) m.delta[l] = h->delta[l];
     m.last_act = h->last_act;
     m.inner_act = h->inner_act;
+    {
+        const char *senv = getenv("GNN_MLP_STATIC");
+        const bool allow_static = !(senv && !strcmp(senv, "0"));
+        h->specialization = (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE &&
+                             (shape_matches<ShapeMnistA>(h) || shape_matches<ShapeMnistB>(h))) ? 1 : 0;
+    }
     for (int bwd = 0; bwd < 2; bwd++) {
         h->mid4_fn[bwd] = mid4_function(h, bwd != 0);
         if (hipFuncSetAttribute(h->mid4_fn[bwd], hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -399,6 +410,20 @@ void plan_mid4(gnn_mlp *h) {
         }
     }
     h->mid4 = true;
+}
+
+// Run-time instantiation of middle4_kernel for this net's shape (jit.h); silent no-op when the
+// net is already specialised, does not take the middle4 path, or hiprtc is unavailable.
+void try_specialize(gnn_mlp *h) {
+    if (!h->mid4 || h->specialization != 0 || h->jit_tried) return;
+    h->jit_tried = true;
+    const char *env = getenv("GNN_MLP_JIT");
+    if (env && !strcmp(env, "0")) return;
+    const jit::Specialised *sp = jit::get_middle4(h->device, h->dims.data(), h->L, h->inner_act, h->out_kind, h->mid4_lds_bytes);
+    if (!sp) return;
+    h->mid4_jit[0] = sp->fn[0];
+    h->mid4_jit[1] = sp->fn[1];
+    h->specialization = 2;
 }
 
 // forward of the fused path; backward = also delta_1..delta_{L-1}
@@ -423,20 +448,26 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
         m4.B = B;
         void *args[] = {&m4};
         // every padded row is processed: rows >= B become zeros
+        const int bw = backward ? 1 : 0;
+        const unsigned grid = (unsigned)(pad_up(B) / 4);
         TimerClass &tc = h->timers[GNN_K_MIDDLE];
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (h->timing && tc.used < 8192) {
             if (tc.used >= tc.start.size()) {
                 hipEvent_t a = nullptr, b = nullptr;
                 if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { tc.start.push_back(a); tc.stop.push_back(b); }
             }
-            if (tc.used < tc.start.size()) {
-                const size_t slot = tc.used++;
-                (void)hipExtLaunchKernel(const_cast<void *>(h->mid4_fn[backward ? 1 : 0]), dim3(pad_up(B) / 4), dim3(1024), args,
-                                         h->mid4_lds_bytes, h->stream, tc.start[slot], tc.stop[slot], 0);
-                return;
-            }
+            if (tc.used < tc.start.size()) { ev0 = tc.start[tc.used]; ev1 = tc.stop[tc.used]; tc.used++; }
         }
-        (void)hipLaunchKernel(h->mid4_fn[backward ? 1 : 0], dim3(pad_up(B) / 4), dim3(1024), args, h->mid4_lds_bytes, h->stream);
+        if (h->mid4_jit[bw]) { // module function: global size is given in threads
+            (void)hipExtModuleLaunchKernel(h->mid4_jit[bw], grid * 1024u, 1, 1, 1024, 1, 1, h->mid4_lds_bytes, h->stream, args,
+                                           nullptr, ev0, ev1, 0);
+        } else if (ev0) {
+            (void)hipExtLaunchKernel(const_cast<void *>(h->mid4_fn[bw]), dim3(grid), dim3(1024), args, h->mid4_lds_bytes,
+                                     h->stream, ev0, ev1, 0);
+        } else {
+            (void)hipLaunchKernel(h->mid4_fn[bw], dim3(grid), dim3(1024), args, h->mid4_lds_bytes, h->stream);
+        }
         return;
     }
     MidParams m = h->mid;
@@ -504,7 +535,19 @@ int export_rows(gnn_mlp *h, const float *src, int ld, int d, int B, double *host
     return GNN_OK;
 }
 
+// A handle that keeps stepping repays the ~0.4 s run-time instantiation (jit.h); never while the
+// stream is being captured into a graph (module loading is not a capturable operation).
+void maybe_specialize(gnn_mlp *h) {
+    if (h->jit_tried || h->specialization != 0 || !h->mid4) return;
+    if (++h->steps_seen < 16) return;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &st) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (st != hipStreamCaptureStatusNone) return;
+    try_specialize(h);
+}
+
 int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step, double momentum) {
+    maybe_specialize(h);
     ScopedTimer tm(h, GNN_K_STEP);
     do_gradient(h, a0, y, B, true, (float)(step / (double)B), (float)momentum);
     h->time++;
@@ -894,6 +937,7 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
     if (n_steps <= 0) return fail(GNN_ERR_BAD_ARG, "n_steps must be positive (NNT:62)");
     const int64_t nb = h->dataset_n / B;
     if (nb <= 0 || first < 0 || first % B != 0) return fail(GNN_ERR_BAD_ARG, "first must be a multiple of B inside the dataset");
+    if (n_steps >= 64) try_specialize(h); // a long run repays the ~0.4 s instantiation
     int s = 0;
     // hipGraph replay: when the request covers whole passes over the nb batches, one pass
     // (nb steps, 3 launches each on the fused path) is captured ONCE from this very stream and
@@ -1063,6 +1107,7 @@ int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int ba
     if (iterations <= 0) return fail(GNN_ERR_BAD_ARG, "iterations must be positive (NNT:62)");
     if (s->master != h->dataset_n) return fail(GNN_ERR_BAD_ARG, "sampler size differs from the dataset");
     if (batch >= s->master) return fail(GNN_ERR_BAD_ARG, "batchSize must be below the data size (NNT:63)");
+    if (iterations >= 64) try_specialize(h);
     std::vector<int32_t> idx((size_t)iterations * batch);
     std::vector<int> cnt((size_t)iterations);
     for (int i = 0; i < iterations; i++) TRY(gnn_sampler_sample(s, batch, idx.data() + (size_t)i * batch, &cnt[i]));
@@ -1106,6 +1151,7 @@ int gnn_mlp_compute_gradient_range(gnn_mlp_t *h, int64_t first, int B) {
     TRY(check_batch(h, B));
     TRY(check_range(h, first, B));
     const float *a0 = h->DX + (size_t)first * h->ld[0];
+    maybe_specialize(h);
     do_gradient(h, a0, h->DY + (size_t)first * h->ld[h->L - 1], B, false, 0.f, 0.f);
     HIP_TRY(hipGetLastError());
     return GNN_OK;
@@ -1135,6 +1181,15 @@ int gnn_mlp_synchronize(gnn_mlp_t *h) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     return GNN_OK;
 }
+
+// ---- shape specialisation ---------------------------------------------------------------------
+int gnn_mlp_specialize(gnn_mlp_t *h) {
+    TRY(check_handle(h));
+    h->jit_tried = false;
+    try_specialize(h);
+    return GNN_OK;
+}
+int gnn_mlp_specialization(const gnn_mlp_t *h) { return h ? h->specialization : -1; }
 
 // ---- measurement ---------------------------------------------------------------------------
 int gnn_mlp_timing_enable(gnn_mlp_t *h, int on) {

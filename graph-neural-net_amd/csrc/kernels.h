@@ -15,8 +15,17 @@
 //   A_l   [B_pad]   rows x ld(d_l)           activations f(z_l), rows >= B are 0
 //   D_l   [B_pad]   rows x ld(d_l)           dE/dz_l
 #pragma once
+#ifdef __HIPCC_RTC__ // compiled at run time by hiprtc (jit.h): its built-in runtime header is implicit
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace gnn {
 
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
     // NaN logit makes EVERY probability NaN, i.e. label 0.
     bool has_nan = false;
     if (p.out_kind == 0) {
-        float mx = -INFINITY;
+        float mx = -__builtin_inff();
         int best = -1;
         for (int c = lane; c < p.n_true; c += 64) {
             const float v = z[c];
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
             if (p.label) p.label[row] = live_row ? best : -1;
         }
     } else {
-        float mx = -INFINITY;
+        float mx = -__builtin_inff();
         int best = -1;
         float l = 0.f;
         for (int c = lane; c < p.n_pad; c += 64) {

@@ -336,7 +336,7 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
         const float *z = smem + m.off_logits + mr * (N + 4);
         const float *y = smem + m.off_y + mr * N;
         float *dimg = smem + m.off_dl[Lm] + mr * (N + 4);
-        float mx = -INFINITY, lsum = 0.f, nan_flag = 0.f; // MT:166-168 NaN rule, see output_layer_kernel
+        float mx = -__builtin_inff(), lsum = 0.f, nan_flag = 0.f; // MT:166-168 NaN rule, see output_layer_kernel
         int best = -1;
         if (OUTK == 0) {
             for (int c = c0; c < nt; c += 16) {

@@ -258,6 +258,17 @@ class NeuralNet:
     def advance_time(self, steps):
         _capi.check(self._lib.gnn_mlp_advance_time(self._h, int(steps)))
 
+    # -- shape specialisation -----------------------------------------------------------------
+    def specialize(self):
+        """Instantiate the fused path's kernels for this net's layer sizes (hiprtc)."""
+        _capi.check(self._lib.gnn_mlp_specialize(self._h))
+        return self.specialization
+
+    @property
+    def specialization(self):
+        """0 generic kernels, 1 prebuilt instantiation, 2 instantiated at run time."""
+        return self._lib.gnn_mlp_specialization(self._h)
+
     # -- measurement --------------------------------------------------------------------------
     def timing_enable(self, on=True):
         _capi.check(self._lib.gnn_mlp_timing_enable(self._h, int(bool(on))))

@@ -195,6 +195,19 @@ int gnn_mlp_synchronize(gnn_mlp_t *h);
  * were only captured, not executed). */
 int gnn_mlp_advance_time(gnn_mlp_t *h, int steps);
 
+/* ---- shape specialisation ---------------------------------------------------------------------
+ * The per-row-block kernel of the fused small-net path is a template over the net's shape; with
+ * compile-time layer sizes it is ~1.5x faster than with sizes read from kernel arguments.
+ * gnn_mlp_specialize instantiates it for THIS net at run time (hiprtc, ~0.4 s once per shape and
+ * process); a handle does it by itself at its 16th gradient computation or when a long training
+ * call (>= 64 steps) starts; env GNN_MLP_JIT=0 turns it off.  Results are bitwise identical
+ * either way.
+ * gnn_mlp_specialization: 0 = generic kernels (sizes from arguments, or the net does not take
+ * the fused path), 1 = prebuilt instantiation (the two MNIST shapes BASELINE.json names),
+ * 2 = instantiated at run time. */
+int gnn_mlp_specialize(gnn_mlp_t *h);
+int gnn_mlp_specialization(const gnn_mlp_t *h);
+
 /* ---- measurement support (bench.py) -------------------------------------------------------
  * Mean duration in microseconds of the kernel class `which` over the launches since the last
  * reset.  Kernel classes are timed with the dispatch's own begin/end timestamps

@@ -405,3 +405,26 @@ def test_argmax_nan_rule(gnn, oracle_mod):
         X = np.random.default_rng(1).random((4, dims[0])) + 0.1
         assert np.array_equal(ref.argmax(X), np.zeros(4, dtype=np.int32))
         assert np.array_equal(net.argmax(X), np.zeros(4, dtype=np.int32))
+
+
+def test_runtime_specialisation_is_bitwise_identical(gnn):
+    """gnn_mlp_specialize (hiprtc instantiation of the fused path's kernel template for this
+    net's layer sizes) changes speed only: same arithmetic, same order, bitwise equal results."""
+    dims, B, nb = [784, 256, 64, 10], 64, 4
+    X, Y = make_batch(dims, B * nb, seed=41, sparse=True)
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    assert a.specialization == 0 and b.specialization == 0
+    assert b.specialize() == 2, "run-time instantiation failed (hiprtc unavailable?)"
+    a.upload_dataset(X, Y); b.upload_dataset(X, Y)
+    for s in range(6):
+        a.gradient_step_range((s % nb) * B, B, 0.0125, 0.9)
+        b.gradient_step_range((s % nb) * B, B, 0.0125, 0.9)
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    assert np.array_equal(a.propagate(X[:B]), b.propagate(X[:B]))
+    assert np.array_equal(a.argmax_range(0, B), b.argmax_range(0, B))
+    # the two shapes BASELINE.json names are prebuilt; a long training call specialises by itself
+    c = gnn.SoftmaxCrossEntropyNeuralNet([784, 300, 100, 10], max_batch=128)
+    assert c.specialization == 1
+    a.train_range(0, B, 64, 0.0125, 0.9)
+    assert a.specialization == 2
