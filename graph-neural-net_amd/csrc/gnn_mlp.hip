@@ -948,13 +948,15 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
     if (nb <= 0 || first < 0 || first % B != 0) return fail(GNN_ERR_BAD_ARG, "first must be a multiple of B inside the dataset");
     if (n_steps >= 64) try_specialize(h); // a long run repays the ~0.4 s instantiation
     int s = 0;
-    // hipGraph replay: when the request covers whole passes over the nb batches, one pass
-    // (nb steps, 3 launches each on the fused path) is captured ONCE from this very stream and
-    // replayed with a single launch per pass; the remainder runs eagerly.  Off while per-kernel
-    // timing is on (timed launches carry events) and on a caller-provided stream (the caller
-    // may be capturing itself); GNN_MLP_GRAPH=0 disables it.
+    // hipGraph replay (opt-in, GNN_MLP_GRAPH=1): when the request covers whole passes over the nb
+    // batches, one pass (nb steps, 3 launches each on the fused path) is captured ONCE from this
+    // very stream and replayed with a single launch per pass; the remainder runs eagerly.  It is
+    // off by default because it buys nothing on one GPU (22.38 vs 22.32 us/step: the kernels
+    // already run back to back) while the capture costs a few ms on the first call.  Never while
+    // per-kernel timing is on (timed launches carry events) or on a caller-provided stream (the
+    // caller may be capturing itself).
     const char *genv = getenv("GNN_MLP_GRAPH");
-    const bool want_graph = !(genv && !strcmp(genv, "0")) && !h->timing && h->stream == h->own_stream &&
+    const bool want_graph = genv && !strcmp(genv, "1") && !h->timing && h->stream == h->own_stream &&
                             nb >= 2 && nb <= 1024 && n_steps >= 2 * nb;
     if (want_graph) {
         const int64_t fb = (first / B) % nb;

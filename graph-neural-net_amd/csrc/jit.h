@@ -103,8 +103,14 @@ inline const Specialised *get_middle4(int device, const int *dims, int L, int ac
         }
         // more than 64 KB of dynamic LDS needs the opt-in, exactly as for the ahead-of-time kernels
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(sp.fn[b]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess)
-            (void)hipGetLastError(); // some runtimes reject the attribute on module functions; the launch decides
+                                (int)lds_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (lds_bytes > 64 * 1024) { // without the opt-in such a launch would be refused: keep the AOT kernels
+                sp.fn[0] = sp.fn[1] = nullptr;
+                sp.log += "\nhipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+                return nullptr;
+            }
+        }
     }
     return &sp;
 }

@@ -373,9 +373,11 @@ def test_more_shapes_take_every_path(gnn, oracle_mod, dims, B, inner):
             assert np.abs(full[l] - (h1[l] + h2[l])).max() <= 2e-5 * np.abs(full[l]).max() + 1e-9
 
 
-def test_train_range_graph_replay_equals_stepwise(gnn):
-    """gnn_mlp_train_range replays a captured hipGraph of one pass when the request covers whole
-    passes: same kernels, same order -> bitwise equal to step-by-step calls; `time` is right."""
+def test_train_range_graph_replay_equals_stepwise(gnn, monkeypatch):
+    """With GNN_MLP_GRAPH=1 gnn_mlp_train_range replays a captured hipGraph of one pass when the
+    request covers whole passes: same kernels, same order -> bitwise equal to step-by-step calls;
+    `time` is right."""
+    monkeypatch.setenv("GNN_MLP_GRAPH", "1")
     dims, B, nb = [784, 300, 100, 10], 128, 5
     X, Y = make_batch(dims, B * nb, seed=33)
     a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
