@@ -272,11 +272,34 @@ void plan_mid4(gnn_mlp *h);
 // Decides whether the net fits the fused path and lays out the middle kernel's LDS.
 void plan_fused(gnn_mlp *h) {
     h->fused = false;
+    h->mid4 = false;
     const char *env = getenv("GNN_MLP_PATH");
     if (env && !strcmp(env, "generic")) return;
     if (h->dtype != GNN_DTYPE_F32) return; // bf16 operands: generic per-layer GEMMs (gemm_bf16.h)
     const int L = h->L, Lm = L - 1;
     if (L < 3 || L > MAX_LAYERS) return;
+    // gradient tiles: every layer's 32x32 tiles in one grid (shared by both middle kernels)
+    {
+        GradParams &g = h->grad;
+        g = GradParams{};
+        g.n_layers = L - 1;
+        int tiles = 0;
+        for (int l = 0; l < L - 1; l++) {
+            GradLayer &gl = g.layer[l];
+            gl.A = h->act[l]; gl.lda = h->ld[l];
+            gl.D = h->delta[l + 1]; gl.ldd = h->ld[l + 1];
+            gl.W = h->W + h->w_off[l]; gl.V = h->V + h->w_off[l]; gl.G = h->G + h->w_off[l];
+            gl.M = h->ld[l]; gl.N = h->ld[l + 1];
+            gl.tiling = make_xcd_tiling((gl.M + 31) / 32, (gl.N + 31) / 32);
+            gl.block_begin = tiles;
+            tiles += gl.tiling.blocks();
+        }
+        h->grad_tiles = tiles;
+    }
+    // preferred: 4-row blocks with LDS-resident middle weights
+    plan_mid4(h);
+    if (h->mid4) { h->fused = true; return; }
+    // fallback: 16-row blocks streaming the middle weights from L2 (they do not fit LDS)
     long mid_w = 0;
     for (int l = 1; l < Lm; l++) mid_w += (long)h->ld[l] * h->ld[l + 1];
     if (mid_w > 160 * 1024) return; // every 16-row block streams all middle weights twice
@@ -313,24 +336,7 @@ void plan_fused(gnn_mlp *h) {
         (void)hipGetLastError();
         return;
     }
-    // gradient tiles: every layer's 32x32 tiles in one grid
-    GradParams &g = h->grad;
-    g = GradParams{};
-    g.n_layers = L - 1;
-    int tiles = 0;
-    for (int l = 0; l < L - 1; l++) {
-        GradLayer &gl = g.layer[l];
-        gl.A = h->act[l]; gl.lda = h->ld[l];
-        gl.D = h->delta[l + 1]; gl.ldd = h->ld[l + 1];
-        gl.W = h->W + h->w_off[l]; gl.V = h->V + h->w_off[l]; gl.G = h->G + h->w_off[l];
-        gl.M = h->ld[l]; gl.N = h->ld[l + 1];
-        gl.tiling = make_xcd_tiling((gl.M + 31) / 32, (gl.N + 31) / 32);
-        gl.block_begin = tiles;
-        tiles += gl.tiling.blocks();
-    }
-    h->grad_tiles = tiles;
     h->fused = true;
-    plan_mid4(h);
 }
 
 // ---- middle4_kernel plan ----------------------------------------------------------------------
