@@ -5,10 +5,10 @@
 //   fwd_first_kernel   A_1 = f(A_0 . W_0)            one 16x16 output tile per workgroup, the K
 //                                                     dimension split over the workgroup's waves
 //                                                     (in-LDS reduction, no global partials)
-//   middle_kernel      per 16-row block of the batch: forward through every remaining layer,
-//                      softmax / loss / delta_{L-1}, and the whole backward-data chain down to
-//                      delta_1 -- all per-sample independent (SCE:164-198, SCE:249-278), so a
-//                      workgroup needs no other workgroup's data
+//   middle4_kernel     (middle4_kernel.h) per 4-row block of the batch: forward through every
+//                      remaining layer, softmax / loss / delta_{L-1}, and the whole backward-data
+//                      chain down to delta_1 -- all per-sample independent (SCE:164-198,
+//                      SCE:249-278), so a workgroup needs no other workgroup's data
 //   grad_update_kernel every layer's G_l = A_l^T . delta_{l+1} (the only cross-sample sum,
 //                      SCE:305-322) with the momentum update (SCE:333-339) fused into the
 //                      epilogue, one launch for all layers
@@ -274,227 +274,6 @@ __global__ __launch_bounds__(256) void grad_update_kernel(GradParams p) {
         }
     }
     GNN_STAMP_AT(p.stamps, 3);
-}
-
-// ------------------------------------------------------------------------------------------
-// middle_kernel: everything between A_1 and delta_1 for one 16-row block of the batch.
-// ------------------------------------------------------------------------------------------
-struct MidParams {
-    int L;                       // layerDims.length
-    int d[MAX_LAYERS], ld[MAX_LAYERS];
-    const float *W[MAX_LAYERS];  // W[l]: weights between layers l and l+1, l = 1..L-2
-    float *act[MAX_LAYERS];      // act[1] (in), act[2..L-2] (out)
-    float *delta[MAX_LAYERS];    // delta[1..L-1] (out)
-    int kp_fwd[MAX_LAYERS];      // K-split of the GEMM producing layer l (l = 2..L-1)
-    int kp_bwd[MAX_LAYERS];      // K-split of the GEMM producing delta_l (l = 1..L-2)
-    int off_act[MAX_LAYERS];     // LDS float offsets: act images, l = 1..L-2
-    int off_logits, off_da, off_db, off_scratch;
-    const float *Y; int ldy;
-    float *prob; float *loss; int32_t *label;
-    int B;
-    int inner_act, out_kind, last_act;
-    int backward;                // 0: forward + output only
-    unsigned long long *stamps;  // diagnostic builds only (STAMP = true): [grid][16] s_memtime values
-};
-
-// C[16 x N] partials: scratch[kp][16][N] = A_lds[16 x Kpart] . B[Kpart x N]
-template <bool B_KC, int NW>
-__device__ __forceinline__ void wg_gemm16(const float *A_lds, int lda, int K, const float *__restrict__ Bg, int ldb,
-                                          int N, int KP, float *scratch, int wave, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-    const int NT = N / 16, k16 = K / 16;
-    for (int item = wave; item < NT * KP; item += NW) {
-        const int nt = item % NT, kp = item / NT;
-        const int c_begin = kp * k16 / KP, c_end = (kp + 1) * k16 / KP;
-        const int n0 = nt * 16;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        constexpr int U = 4;
-        for (int cb = c_begin; cb < c_end; cb += U) {
-            f32x4 a[U], b[U];
-#pragma unroll
-            for (int i = 0; i < U; i++) {
-                const int k = (cb + i) * 16 + 4 * fq;
-                if (cb + i < c_end) {
-                    if (B_KC) {
-                        b[i] = *reinterpret_cast<const f32x4 *>(Bg + (size_t)(n0 + fr) * ldb + k);
-                    } else {
-                        const float *w = Bg + (size_t)k * ldb + n0 + fr;
-                        b[i] = (f32x4){w[0], w[ldb], w[2 * ldb], w[3 * ldb]};
-                    }
-                    a[i] = *reinterpret_cast<const f32x4 *>(A_lds + fr * lda + k);
-                } else {
-                    a[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    b[i] = a[i];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < U; i++) {
-                if (i & 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], b[i][j], acc1, 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], b[i][j], acc0, 0, 0, 0);
-                }
-            }
-        }
-        const f32x4 acc = acc0 + acc1;
-        float *dst = scratch + (size_t)kp * 16 * N + n0 + fr;
-#pragma unroll
-        for (int r = 0; r < 4; r++) dst[(fq * 4 + r) * N] = acc[r];
-    }
-}
-
-// STAMP builds record s_memtime at every phase boundary into p.stamps (never into an output);
-// the shipped instantiation has STAMP = false and executes no stamp.
-#define GNN_STAMP(i)                                                                          \
-    do {                                                                                      \
-        if (STAMP && threadIdx.x == 0) p.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-
-template <int NW, bool STAMP = false>
-__global__ __launch_bounds__(NW * 64) void middle_kernel(MidParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NT_ = NW * 64;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int row0 = blockIdx.x * 16;
-    const int Lm = p.L - 1;
-    GNN_STAMP(0);
-
-    // stage A_1 rows of this block (k-contiguous image, row stride ld+4)
-    {
-        const int ld1 = p.ld[1], lds1 = ld1 + 4, q4 = ld1 / 4;
-        float *dst = smem + p.off_act[1];
-        const float *src = p.act[1] + (size_t)row0 * ld1;
-        for (int e = t; e < 16 * q4; e += NT_) {
-            const int m = e / q4, q = e - m * q4;
-            *reinterpret_cast<float4 *>(dst + m * lds1 + q * 4) = *reinterpret_cast<const float4 *>(src + (size_t)m * ld1 + q * 4);
-        }
-    }
-    __syncthreads();
-    GNN_STAMP(1);
-
-    // forward: layers 2 .. L-1 (SCE:172-194)
-    for (int l = 2; l <= Lm; l++) {
-        const int K = p.ld[l - 1], N = p.ld[l], KP = p.kp_fwd[l];
-        wg_gemm16<false, NW>(smem + p.off_act[l - 1], K + 4, K, p.W[l - 1], N, N, KP, smem + p.off_scratch, wave, lane);
-        __syncthreads();
-        GNN_STAMP(2 * l - 2);
-        const bool last = (l == Lm);
-        float *dst = smem + (last ? p.off_logits : p.off_act[l]);
-        const int ldsn = N + 4;
-        for (int e = t; e < 16 * N; e += NT_) {
-            const int m = e / N, n = e - m * N;
-            float v = 0.f;
-            for (int kp = 0; kp < KP; kp++) v += smem[p.off_scratch + (kp * 16 + m) * N + n];
-            const bool live = (row0 + m < p.B) && (n < p.d[l]);
-            if (last) {
-                dst[m * ldsn + n] = live ? v : 0.f;
-            } else {
-                const float a = live ? act_fn(p.inner_act, v) : 0.f;
-                dst[m * ldsn + n] = a;
-                p.act[l][(size_t)(row0 + m) * N + n] = a;
-            }
-        }
-        __syncthreads();
-        GNN_STAMP(2 * l - 1);
-    }
-
-    // output layer: one wave per row (SCE:357-376, 249-251, 213-217 / GNN:215-218, 267-271; MT:166-168)
-    {
-        const int N = p.ld[Lm], nt = p.d[Lm], ldsn = N + 4;
-        float *da = smem + p.off_da;
-        for (int m = wave; m < 16; m += NW) {
-            const int row = row0 + m;
-            const bool live_row = row < p.B;
-            const float *z = smem + p.off_logits + m * ldsn;
-            const float *y = p.Y ? p.Y + (size_t)row * p.ldy : nullptr;
-            float mx = -__builtin_inff(), l = 0.f;
-            int best = -1;
-            bool has_nan = false; // MT:166-168 NaN rule, see output_layer_kernel
-            if (p.out_kind == 0) {
-                for (int c = lane; c < nt; c += 64) {
-                    const float v = z[c];
-                    has_nan |= (v != v);
-                    if (v >= mx) { mx = v; best = c; }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(mx, o);
-                    const int ob = __shfl_xor(best, o);
-                    if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
-                }
-                float s = 0.f;
-                for (int c = lane; c < nt; c += 64) s += __expf(z[c] - mx);
-                s = wave_sum(s);
-                const float inv = 1.f / s, lse = mx + __logf(s);
-                for (int c = lane; c < N; c += 64) {
-                    const bool live = live_row && c < nt;
-                    const float pr = live ? __expf(z[c] - mx) * inv : 0.f;
-                    const float yy = (live && y) ? y[c] : 0.f;
-                    if (p.prob) p.prob[(size_t)row * N + c] = pr;
-                    const float d = live ? pr - yy : 0.f;
-                    da[m * ldsn + c] = d;
-                    if (p.backward) p.delta[Lm][(size_t)row * N + c] = d;
-                    if (live && yy != 0.f) l += yy * (lse - z[c]);
-                }
-            } else {
-                for (int c = lane; c < N; c += 64) {
-                    const bool live = live_row && c < nt;
-                    const float a = act_fn(p.last_act, z[c]);
-                    const float yy = (live && y) ? y[c] : 0.f;
-                    const float df = a - yy;
-                    if (p.prob) p.prob[(size_t)row * N + c] = live ? a : 0.f;
-                    const float d = live ? df * act_prime_from_a(p.last_act, a) : 0.f;
-                    da[m * ldsn + c] = d;
-                    if (p.backward) p.delta[Lm][(size_t)row * N + c] = d;
-                    if (live) {
-                        l += 0.5f * df * df;
-                        if (c == 0) has_nan = (a != a);
-                        if (a >= mx) { mx = a; best = c; }
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(mx, o);
-                    const int ob = __shfl_xor(best, o);
-                    if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
-                }
-            }
-            if (__any(has_nan)) best = 0;
-            l = wave_sum(l);
-            if (lane == 0) {
-                if (p.loss) p.loss[row] = live_row ? l : 0.f;
-                if (p.label) p.label[row] = live_row ? best : -1;
-            }
-        }
-    }
-    if (!p.backward) return;
-    __syncthreads();
-    GNN_STAMP(2 * Lm);
-
-    // backward data: delta_l = (delta_{l+1} . W_l^T) * f'(z_l), l = L-2 .. 1 (SCE:262-278)
-    int cur = p.off_da, nxt = p.off_db;
-    for (int l = Lm - 1; l >= 1; l--) {
-        const int K = p.ld[l + 1], N = p.ld[l], KP = p.kp_bwd[l];
-        wg_gemm16<true, NW>(smem + cur, K + 4, K, p.W[l], K, N, KP, smem + p.off_scratch, wave, lane);
-        __syncthreads();
-        GNN_STAMP(2 * Lm + 1 + 2 * (Lm - 1 - l));
-        const int ldsn = N + 4;
-        const float *aimg = smem + p.off_act[l];
-        for (int e = t; e < 16 * N; e += NT_) {
-            const int m = e / N, n = e - m * N;
-            float v = 0.f;
-            for (int kp = 0; kp < KP; kp++) v += smem[p.off_scratch + (kp * 16 + m) * N + n];
-            const bool live = (row0 + m < p.B) && (n < p.d[l]);
-            const float d = live ? v * act_prime_from_a(p.inner_act, aimg[m * ldsn + n]) : 0.f;
-            smem[nxt + m * ldsn + n] = d;
-            p.delta[l][(size_t)(row0 + m) * N + n] = d;
-        }
-        __syncthreads();
-        GNN_STAMP(2 * Lm + 2 + 2 * (Lm - 1 - l));
-        const int tmp = cur; cur = nxt; nxt = tmp;
-    }
 }
 
 } // namespace gnn

@@ -70,10 +70,9 @@ struct gnn_mlp {
 
     // fused small-net path (fused_kernels.h): plan made once at create
     bool fused = false;
-    MidParams mid{};
-    size_t mid_lds_bytes = 0;
     GradParams grad{};
     int grad_tiles = 0;
+    bool mid_generic = false; // middle weights fit neither LDS plan: per-layer GEMMs between fwd_first and grad_update
     bool mid4 = false;        // middle4_kernel (LDS-resident weights) instead of middle_kernel
     Mid4Params mid4p{};
     size_t mid4_lds_bytes = 0;
@@ -180,10 +179,10 @@ void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
 
 // ---- forward (SCE:164-198): a0 = f(x) rows, B live rows ------------------------------------
 // leaves act[1..L-2], logits; the output kernel is launched by the caller via run_output.
-void forward(gnn_mlp *h, const float *a0, int B) {
+void forward(gnn_mlp *h, const float *a0, int B, int first_l = 1) {
     const int B_pad = pad_up(B);
-    const float *in = a0;
-    for (int l = 1; l < h->L; l++) {
+    const float *in = (first_l == 1) ? a0 : h->act[first_l - 1];
+    for (int l = first_l; l < h->L; l++) {
         GemmParams p{};
         p.A = in; p.lda = h->ld[l - 1];
         p.B = h->W + h->w_off[l - 1]; p.ldb = h->ld[l];
@@ -219,7 +218,8 @@ void run_output(gnn_mlp *h, const float *y, int B, bool want_prob, bool want_del
 // ---- backward (SCE:229-287) + gradient / update -------------------------------------------
 // fused_update: G_l is consumed by the SGD epilogue and never written (single GPU);
 // otherwise G_l goes to the flat gradient buffer for the caller's all-reduce.
-void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_over_b, float momentum) {
+void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_over_b, float momentum,
+              bool data_only = false) {
     const int B_pad = pad_up(B);
     for (int l = h->L - 2; l >= 0; l--) {
         if (l >= 1) { // delta_l = (delta_{l+1} . W_l^T) * f'(z_l)   -- before W_l is touched
@@ -233,6 +233,7 @@ void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_
             p.act = h->inner_act;
             launch_gemm<true, true, EPI_DACT>(h, -1, p);
         }
+        if (data_only) continue; // the caller forms every G_l in one grad_update_kernel launch
         GemmParams g{}; // G_l = A_l^T . delta_{l+1}
         g.A = (l == 0) ? a0 : h->act[l]; g.lda = h->ld[l];
         g.B = h->delta[l + 1]; g.ldb = h->ld[l + 1];
@@ -253,19 +254,7 @@ void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_
 }
 
 // ---- fused small-net path ---------------------------------------------------------------------
-constexpr int MID_NW = 16;   // waves per middle_kernel workgroup
 constexpr int FIRST_NW = 8;  // waves per fwd_first_kernel workgroup (K split in-LDS)
-
-int pick_kp(int NT, int k16, int N) {
-    int best = 1;
-    long best_cost = -1;
-    for (int kp = 1; kp <= k16 && kp <= 8; kp++) {
-        if ((long)kp * 16 * N * 4 > 48 * 1024) break;
-        const long cost = (long)((NT * kp + MID_NW - 1) / MID_NW) * ((k16 + kp - 1) / kp);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = kp; }
-    }
-    return best;
-}
 
 void plan_mid4(gnn_mlp *h);
 
@@ -299,43 +288,10 @@ void plan_fused(gnn_mlp *h) {
     // preferred: 4-row blocks with LDS-resident middle weights
     plan_mid4(h);
     if (h->mid4) { h->fused = true; return; }
-    // fallback: 16-row blocks streaming the middle weights from L2 (they do not fit LDS)
-    long mid_w = 0;
-    for (int l = 1; l < Lm; l++) mid_w += (long)h->ld[l] * h->ld[l + 1];
-    if (mid_w > 160 * 1024) return; // every 16-row block streams all middle weights twice
-    MidParams &m = h->mid;
-    m = MidParams{};
-    m.L = L;
-    int off = 0, maxld = 0, scratch = 0;
-    for (int l = 0; l < L; l++) { m.d[l] = h->dims[l]; m.ld[l] = h->ld[l]; }
-    for (int l = 1; l < Lm; l++) { m.off_act[l] = off; off += 16 * (h->ld[l] + 4); }
-    m.off_logits = off; off += 16 * (h->ld[Lm] + 4);
-    for (int l = 1; l <= Lm; l++) maxld = h->ld[l] > maxld ? h->ld[l] : maxld;
-    m.off_da = off; off += 16 * (maxld + 4);
-    m.off_db = off; off += 16 * (maxld + 4);
-    for (int l = 2; l <= Lm; l++) {
-        m.kp_fwd[l] = pick_kp(h->ld[l] / 16, h->ld[l - 1] / 16, h->ld[l]);
-        const int s = m.kp_fwd[l] * 16 * h->ld[l];
-        scratch = s > scratch ? s : scratch;
-    }
-    for (int l = Lm - 1; l >= 1; l--) {
-        m.kp_bwd[l] = pick_kp(h->ld[l] / 16, h->ld[l + 1] / 16, h->ld[l]);
-        const int s = m.kp_bwd[l] * 16 * h->ld[l];
-        scratch = s > scratch ? s : scratch;
-    }
-    m.off_scratch = off; off += scratch;
-    const size_t bytes = (size_t)off * sizeof(float);
-    if (bytes > 150 * 1024) return;
-    h->mid_lds_bytes = bytes;
-    for (int l = 1; l < Lm; l++) m.W[l] = h->W + h->w_off[l];
-    for (int l = 1; l < Lm; l++) m.act[l] = h->act[l];
-    for (int l = 1; l <= Lm; l++) m.delta[l] = h->delta[l];
-    m.inner_act = h->inner_act; m.out_kind = h->out_kind; m.last_act = h->last_act;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&middle_kernel<MID_NW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        return;
-    }
+    // the middle weights do not fit LDS: per-layer tiled GEMMs for the middle, still bracketed by
+    // the one-launch first layer and the one-launch gradient+update (a 16-row kernel that streamed
+    // the middle weights from L2 was 15-40 % slower than this on every such shape and was removed)
+    h->mid_generic = true;
     h->fused = true;
 }
 
@@ -390,7 +346,7 @@ const void *mid4_function(const gnn_mlp *h, bool bwd) {
 void plan_mid4(gnn_mlp *h) {
     h->mid4 = false;
     const char *env = getenv("GNN_MLP_PATH");
-    if (env && !strcmp(env, "fused16")) return;
+    if (env && !strcmp(env, "nomid4")) return; // tests: force the per-layer middle
     const int L = h->L, Lm = L - 1;
     Mid4Params &m = h->mid4p;
     m = Mid4Params{};
@@ -485,13 +441,12 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
         }
         return;
     }
-    MidParams m = h->mid;
-    m.Y = y; m.ldy = h->ld[h->L - 1];
-    m.prob = want_prob ? h->prob : nullptr;
-    m.loss = want_loss ? h->lossv : nullptr;
-    m.label = want_label ? h->labels : nullptr;
-    m.B = B; m.backward = backward ? 1 : 0;
-    launch_timed(h, GNN_K_MIDDLE, middle_kernel<MID_NW>, dim3(B_pad / 16), dim3(MID_NW * 64), h->mid_lds_bytes, m);
+    if (h->mid_generic) {
+        forward(h, a0, B, 2);
+        run_output(h, y, B, want_prob, backward, want_loss, want_label);
+        if (backward) ::backward(h, a0, B, false, 0.f, 0.f, true);
+        return;
+    }
 }
 
 void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_over_b, float momentum) {

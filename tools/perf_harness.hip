@@ -32,20 +32,6 @@ int main(int argc, char **argv) {
 
     FwdFirstParams f{}; f.A = act[0]; f.lda = ld[0]; f.W = W; f.ldw = ld[1]; f.C = act[1]; f.ldc = ld[1];
     f.M = Bp; f.N = ld[1]; f.K = ld[0]; f.m_true = B; f.n_true = dims[1]; f.act = 0; f.apply_act = 1; f.tiling = make_xcd_tiling(f.M / 16, f.N / 16);
-    MidParams m{}; m.L = L; int off = 0, maxld = 0;
-    for (int l = 0; l < L; l++) { m.d[l] = dims[l]; m.ld[l] = ld[l]; }
-    for (int l = 1; l < 3; l++) { m.off_act[l] = off; off += 16 * (ld[l] + 4); }
-    m.off_logits = off; off += 16 * (ld[3] + 4);
-    for (int l = 1; l < L; l++) maxld = std::max(maxld, ld[l]);
-    m.off_da = off; off += 16 * (maxld + 4); m.off_db = off; off += 16 * (maxld + 4);
-    m.kp_fwd[2] = argc > 2 ? atoi(argv[2]) : 2; m.kp_fwd[3] = 7; m.kp_bwd[2] = 1; m.kp_bwd[1] = argc > 3 ? atoi(argv[3]) : 2;
-    m.off_scratch = off; off += 3 * 16 * 304;
-    for (int l = 1; l < 3; l++) { m.W[l] = W + woff[l]; m.act[l] = act[l]; }
-    for (int l = 1; l < L; l++) m.delta[l] = delta[l];
-    m.Y = Y; m.ldy = ld[3]; m.loss = lossv; m.label = labels; m.B = B; m.backward = 1; m.stamps = stamps;
-    size_t lds = (size_t)off * 4;
-    CK(hipFuncSetAttribute((const void *)&middle_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CK(hipFuncSetAttribute((const void *)&middle_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GradParams g{}; g.n_layers = 3; int tiles = 0;
     for (int l = 0; l < 3; l++) { GradLayer &gl = g.layer[l]; gl.A = act[l]; gl.lda = ld[l]; gl.D = delta[l + 1]; gl.ldd = ld[l + 1];
         gl.W = W + woff[l]; gl.V = V + woff[l]; gl.G = G + woff[l]; gl.M = ld[l]; gl.N = ld[l + 1]; gl.tiling = make_xcd_tiling((gl.M + 31) / 32, (gl.N + 31) / 32); gl.block_begin = tiles; tiles += gl.tiling.blocks(); }
@@ -75,14 +61,11 @@ int main(int argc, char **argv) {
     };
     auto k_first = [&]() { hipLaunchKernelGGL((fwd_first_kernel<8>), dim3(f.tiling.blocks()), dim3(512), 0, s, f); };
     auto k_first16 = [&]() { hipLaunchKernelGGL((fwd_first_kernel<16>), dim3(f.tiling.blocks()), dim3(1024), 0, s, f); };
-    auto k_mid = [&]() { hipLaunchKernelGGL((middle_kernel<16, false>), dim3(Bp / 16), dim3(1024), lds, s, m); };
-    auto k_mid_stamp = [&]() { hipLaunchKernelGGL((middle_kernel<16, true>), dim3(Bp / 16), dim3(1024), lds, s, m); };
     auto k_grad = [&]() { hipLaunchKernelGGL((grad_update_kernel<true>), dim3(tiles), dim3(256), 0, s, g); };
     auto k_grad_nf = [&]() { hipLaunchKernelGGL((grad_update_kernel<false>), dim3(tiles), dim3(256), 0, s, g); };
     time_it("fwd_first<8>", 500, k_first);
     time_it("fwd_first<16>", 500, k_first16);
     time_it("fwd_first<8,ACT=leaky>", 500, [&]() { hipLaunchKernelGGL((fwd_first_kernel<8, false, 0>), dim3(f.tiling.blocks()), dim3(512), 0, s, f); });
-    time_it("middle<16>", 500, k_mid);
     auto k_mid4r = [&]() { hipLaunchKernelGGL((middle4_kernel<RuntimeShape<4>, 0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
     auto k_mid4 = [&]() { hipLaunchKernelGGL((middle4_kernel<SS, 0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
     time_it("middle4 runtime shape", 500, k_mid4r);
@@ -90,20 +73,6 @@ int main(int argc, char **argv) {
     time_it("step with middle4 static", 500, [&]() { k_first(); k_mid4(); k_grad(); });
     time_it("grad_update<fused>", 500, k_grad);
     time_it("grad_update<store G>", 500, k_grad_nf);
-    time_it("whole step (3 launches)", 500, [&]() { k_first(); k_mid(); k_grad(); });
-    {   // 50 steps captured in one hipGraph: per-step time without host launch limits
-        hipGraph_t graph; hipGraphExec_t exec;
-        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < 50; i++) { k_first(); k_mid(); k_grad(); }
-        CK(hipStreamEndCapture(s, &graph));
-        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        for (int i = 0; i < 3; i++) CK(hipGraphLaunch(exec, s));
-        CK(hipEventRecord(e0, s));
-        for (int i = 0; i < 10; i++) CK(hipGraphLaunch(exec, s));
-        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("%-28s %8.2f us per step\n", "graph replay (50 steps/graph)", ms * 1000.f / 500);
-    }
     {
         f.stamps = stamps; g.stamps = stamps;
         for (int rep = 0; rep < 2; rep++) {
@@ -146,15 +115,6 @@ int main(int argc, char **argv) {
         for (int wg : {0, 31, 32, 63}) printf("middle4 stamps wg %d%s: load+stage=%llu fwdL2=%llu fwdL3=%llu output=%llu bwd2=%llu bwd1=%llu total=%llu\n", wg % 32, wg >= 32 ? " (2nd pass)" : "",
             hs[wg*16+1]-hs[wg*16], hs[wg*16+6]-hs[wg*16+1], hs[wg*16+7]-hs[wg*16+6], hs[wg*16+3]-hs[wg*16+2], hs[wg*16+12]-hs[wg*16+3], hs[wg*16+11]-hs[wg*16+12], hs[wg*16+4]-hs[wg*16]);
         }
-    }
-    k_mid_stamp(); CK(hipStreamSynchronize(s));
-    std::vector<unsigned long long> hs(Bp / 16 * 16);
-    CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
-    const char *names[] = {"stage A1", "gemm L2", "epi L2", "gemm L3", "epi L3", "output", "gemm d2", "epi d2", "gemm d1", "epi d1"};
-    for (int wg : {0, Bp / 16 - 1}) {
-        printf("middle stamps, workgroup %d (cycles @ memtime):", wg);
-        for (int i = 1; i <= 10; i++) printf(" %s=%llu", names[i - 1], hs[wg * 16 + i] - hs[wg * 16 + i - 1]);
-        printf(" total=%llu\n", hs[wg * 16 + 10] - hs[wg * 16]);
     }
     return 0;
 }
