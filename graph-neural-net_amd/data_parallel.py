@@ -35,6 +35,7 @@ class HipEngine:
         self.net = net
         self.torch = torch
         self.grad_tensor = torch.zeros(net.grad_elems, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # the fill ran on torch's current stream; the kernels may use another
         self.stream = stream if stream is not None else torch.cuda.current_stream()
         net.set_stream(self.stream.cuda_stream)
         net.bind_grad_buffer(self.grad_tensor.data_ptr(), self.grad_tensor.numel())
