@@ -262,6 +262,7 @@ void plan_mid4(gnn_mlp *h);
 void plan_fused(gnn_mlp *h) {
     h->fused = false;
     h->mid4 = false;
+    h->mid_generic = false;
     const char *env = getenv("GNN_MLP_PATH");
     if (env && !strcmp(env, "generic")) return;
     if (h->dtype != GNN_DTYPE_F32) return; // bf16 operands: generic per-layer GEMMs (gemm_bf16.h)
@@ -388,9 +389,8 @@ void try_specialize(gnn_mlp *h) {
     h->specialization = 2;
 }
 
-// forward of the fused path; backward = also delta_1..delta_{L-1}
-void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
-                   bool want_loss, bool want_label) {
+// first layer in one launch: a 16x16 tile per workgroup, K split over the waves
+void launch_fwd_first(gnn_mlp *h, const float *a0, int B) {
     const int B_pad = pad_up(B);
     FwdFirstParams f{};
     f.A = a0; f.lda = h->ld[0];
@@ -410,7 +410,13 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
     case 3: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 3>, fg, fb, 0, f); break;
     default: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 4>, fg, fb, 0, f); break;
     }
-    if (h->mid4) {
+}
+
+// forward of the middle4 path; backward = also delta_1..delta_{L-1}
+void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
+                   bool want_loss, bool want_label) {
+    launch_fwd_first(h, a0, B);
+    {
         Mid4Params m4 = h->mid4p;
         m4.Y = y; m4.ldy = h->ld[h->L - 1];
         m4.prob = want_prob ? h->prob : nullptr;
@@ -439,13 +445,6 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
         } else {
             (void)hipLaunchKernel(h->mid4_fn[bw], dim3(grid), dim3(1024), args, h->mid4_lds_bytes, h->stream);
         }
-        return;
-    }
-    if (h->mid_generic) {
-        forward(h, a0, B, 2);
-        run_output(h, y, B, want_prob, backward, want_loss, want_label);
-        if (backward) ::backward(h, a0, B, false, 0.f, 0.f, true);
-        return;
     }
 }
 
@@ -459,21 +458,59 @@ void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float
     else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<false>, dim3(h->grad_tiles), dim3(256), 0, g);
 }
 
+// Nets whose middle weights exceed LDS: per-layer GEMMs for the middle, and per CALL which of the two
+// one-launch kernels still pays. Both trade operand reuse for launch count and occupancy -- a
+// 16x16 (first layer) or 32x32 (gradient) tile re-reads its operands from L2 4-16x more often than
+// the 64/128-wide GEMM tiles -- so they win while the GEMM grids cannot fill the chip and lose once
+// they can (4096-2048-2048-1024 at 512 rows: 692 us with both, 517 us with neither).
+struct HybridChoice { bool first, grad; };
+HybridChoice hybrid_choice(const gnn_mlp *h, int B) {
+    HybridChoice c{true, true};
+    const char *env = getenv("GNN_MLP_HYBRID"); // tests/development: bit 0 = fwd_first, bit 1 = grad_update
+    if (env) { const int m = atoi(env); c.first = (m & 1) != 0; c.grad = (m & 2) != 0; return c; }
+    const int B_pad = pad_up(B);
+    c.first = pick_tile(B_pad, h->ld[1]) == 32;
+    int64_t big = 0, all = 0; // gradient elements in layers whose GEMM grid would fill the chip on its own
+    for (int l = 0; l + 1 < h->L; l++) {
+        const int64_t e = (int64_t)h->ld[l] * h->ld[l + 1];
+        all += e;
+        if (pick_tile(h->ld[l], h->ld[l + 1]) == 128) big += e;
+    }
+    c.grad = big * 2 < all;
+    return c;
+}
+
 // the three shapes every entry point is made of
 void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_prob, bool want_loss, bool want_label) {
-    if (h->fused) { fused_forward(h, a0, y, B, false, want_prob, want_loss, want_label); return; }
-    forward(h, a0, B);
+    if (h->mid4) { fused_forward(h, a0, y, B, false, want_prob, want_loss, want_label); return; }
+    if (h->mid_generic && hybrid_choice(h, B).first) {
+        launch_fwd_first(h, a0, B);
+        forward(h, a0, B, 2);
+    } else {
+        forward(h, a0, B);
+    }
     run_output(h, y, B, want_prob, false, want_loss, want_label);
 }
 void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum) {
-    if (h->fused) {
+    if (h->mid4) {
         fused_forward(h, a0, y, B, true, false, false, false);
         fused_gradient(h, a0, B, fused_update, step_over_b, momentum);
         return;
     }
-    forward(h, a0, B);
+    const HybridChoice c = h->mid_generic ? hybrid_choice(h, B) : HybridChoice{false, false};
+    if (c.first) {
+        launch_fwd_first(h, a0, B);
+        forward(h, a0, B, 2);
+    } else {
+        forward(h, a0, B);
+    }
     run_output(h, y, B, false, true, false, false);
-    backward(h, a0, B, fused_update, step_over_b, momentum);
+    if (c.grad) {
+        backward(h, a0, B, false, 0.f, 0.f, true); // delta_1..delta_{L-2} only
+        fused_gradient(h, a0, B, fused_update, step_over_b, momentum);
+    } else {
+        backward(h, a0, B, fused_update, step_over_b, momentum);
+    }
 }
 
 int check_batch(const gnn_mlp *h, int B) {

@@ -98,9 +98,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
     constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256; // float4 per thread per tile
     static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
-    float4 ra[NA], rb[NB];
+    // TWO register stages for tiles up to 64x64: a single tile of prefetch -- ~1000 cycles of MFMAs
+    // on a 64x64 tile, 256 on a 32x32 one -- does not cover the >=2000 cycles of memory latency;
+    // the loads of tile t+2 are issued before tile t is multiplied
+    float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
 
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](int k0, float4 (&ra)[NA], float4 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int idx = t + i * 256;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             rb[i] = v;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](const float4 (&ra)[NA], const float4 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int idx = t + i * 256;
@@ -173,11 +176,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int a_base = fq * LDAS + wm * (TM * 16) + fr;
     const int b_base = fq * LDBS + wn * (TN * 16) + fr;
 
-    load_tiles(0);
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
-        store_tiles();
-        __syncthreads();
-        if (k0 + BK < p.K) load_tiles(k0 + BK); // next tile's HBM/L2 latency hides under the MFMAs
+    auto multiply = [&]() {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             float a[TM], b[TN];
@@ -191,7 +190,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 for (int j = 0; j < TN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+    };
+    constexpr bool TWO_STAGES = (BM <= 64); // 128x128 tiles: the second stage would cost a wave of occupancy
+    load_tiles(0, ra0, rb0);
+    if (TWO_STAGES) {
+        if (BK < p.K) load_tiles(BK, ra1, rb1);
+        for (int k0 = 0; k0 < p.K; k0 += 2 * BK) { // two tiles per trip so that the stages keep their names
+            store_tiles(ra0, rb0);
+            __syncthreads();
+            if (k0 + 2 * BK < p.K) load_tiles(k0 + 2 * BK, ra0, rb0);
+            multiply();
+            __syncthreads();
+            if (k0 + BK < p.K) {
+                store_tiles(ra1, rb1);
+                __syncthreads();
+                if (k0 + 3 * BK < p.K) load_tiles(k0 + 3 * BK, ra1, rb1);
+                multiply();
+                __syncthreads();
+            }
+        }
+    } else {
+        for (int k0 = 0; k0 < p.K; k0 += BK) {
+            store_tiles(ra0, rb0);
+            __syncthreads();
+            if (k0 + BK < p.K) load_tiles(k0 + BK, ra0, rb0); // next tile's latency hides under the MFMAs
+            multiply();
+            __syncthreads();
+        }
     }
 
     // epilogue: C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg

@@ -373,6 +373,36 @@ def test_more_shapes_take_every_path(gnn, oracle_mod, dims, B, inner):
             assert np.abs(full[l] - (h1[l] + h2[l])).max() <= 2e-5 * np.abs(full[l]).max() + 1e-9
 
 
+@pytest.mark.parametrize("mask", ["0", "1", "2", "3", None])
+def test_hybrid_choices_agree_with_oracle(gnn, oracle_mod, monkeypatch, mask):
+    """Nets whose middle weights exceed LDS pick per call between the one-launch first-layer /
+    gradient kernels and the per-layer GEMMs (hybrid_choice in gnn_mlp.hip); GNN_MLP_HYBRID forces
+    each of the four combinations. All must match the oracle, fused update and gradient export."""
+    import os
+    if os.environ.get("GNN_MLP_PATH"):
+        pytest.skip("path forced by the environment")
+    if mask is None: monkeypatch.delenv("GNN_MLP_HYBRID", raising=False)
+    else: monkeypatch.setenv("GNN_MLP_HYBRID", mask)
+    dims, B = [200, 512, 272, 10], 27
+    X, Y = make_batch(dims, B, seed=77, sparse=True)
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    ref = oracle_mod.OracleNet(dims)
+    ref.set_alloc_per_sample(0)
+    assert np.abs(net.propagate(X) - ref.propagate(X)).max() <= P_ATOL
+    g = net.calculateWeightGradient(X, Y)
+    gr = sum(ref.calculate_weight_gradient(X[b], Y[b]) for b in range(B))
+    off = 0
+    for l in range(len(dims) - 1):
+        n = dims[l] * dims[l + 1]
+        grl = gr[off:off + n].reshape(dims[l], dims[l + 1]); off += n
+        assert np.abs(g[l] - grl).max() <= 3e-5 * np.abs(grl).max() + 1e-9, "layer %d" % l
+    for s in range(3):
+        net.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+        ref.gradient_step(X, Y, 0.0125, 0.9)
+    assert np.abs(net.get_weights() - ref.get_weights()).max() <= 3 * W_ATOL
+    assert np.abs(net.get_momentum() - ref.get_momentum()).max() <= 3 * W_ATOL
+
+
 def test_train_range_graph_replay_equals_stepwise(gnn, monkeypatch):
     """With GNN_MLP_GRAPH=1 gnn_mlp_train_range replays a captured hipGraph of one pass when the
     request covers whole passes: same kernels, same order -> bitwise equal to step-by-step calls;
