@@ -42,9 +42,9 @@ struct Mid4Plan {
     int off_logits, off_y, off_scratch;
     int ks_fwd[MAX_LAYERS];  // K splits of the product giving layer l (l = 2..L-1)
     int ks_bwd[MAX_LAYERS];  // K splits of the product giving delta_l (l = 1..L-2)
-    int w_total4;            // float4s in all weight images
-    int w_begin4[MAX_LAYERS];
-    unsigned long long w_inv_c4[MAX_LAYERS]; // ceil(2^32 / c4) (2^32 itself when c4 = 1): row = (idx * inv) >> 32
+    // staging of weight image l: slabs of st_rpt[l] rows x c4 = kr[l+1]/4 float4s, one float4 per thread
+    int st_rpt[MAX_LAYERS], st_trips[MAX_LAYERS], st_begin[MAX_LAYERS], st_total; // slabs per layer / first slot / all
+    unsigned st_inv_c4[MAX_LAYERS]; // ceil(2^22 / c4): thread -> slab row = (t * inv) >> 22 (exact for t < 1024, c4 <= 256)
     int lds_floats;          // total dynamic LDS, floats
     bool ok;
 };
@@ -75,14 +75,16 @@ __host__ __device__ constexpr Mid4Plan make_mid4_plan(const int *dims, int L) {
     for (int l = 2; l <= Lm; l++) { m.off_dl[l] = off; off += 4 * (m.ld[l] + 4); }
     m.off_y = off; off += 4 * m.ld[Lm];
     m.off_scratch = off;
-    m.w_total4 = 0;
+    m.st_total = 0;
     for (int l = 1; l < Lm; l++) {
         const int c4 = m.kr[l + 1] / 4; // float4s copied per row (the padding columns stay in HBM)
-        m.w_begin4[l] = m.w_total4;
-        m.w_total4 += m.kr[l] * c4;
-        m.w_inv_c4[l] = ((1ull << 32) + c4 - 1) / c4;
+        if (c4 > 256) return m;         // (the column-group limit below says the same)
+        m.st_rpt[l] = 1024 / c4;
+        m.st_trips[l] = (m.kr[l] + m.st_rpt[l] - 1) / m.st_rpt[l];
+        m.st_begin[l] = m.st_total;
+        m.st_total += m.st_trips[l];
+        m.st_inv_c4[l] = ((1u << 22) + c4 - 1) / c4;
     }
-    if (m.w_total4 >= (1 << 20)) return m;
     const int budget = (160 * 1024) / 4 - 64 - off; // floats left for the K-split partials
     if (budget <= 0) return m;
     int scratch = 0;
@@ -218,7 +220,8 @@ __device__ __forceinline__ void rowblock_product(const float *A_img, int lda, co
     for (int i = 0; i < 4; i++) partial[i * gw + n0 + lane] = acc[i];
 }
 
-template <int NL, int ACT_T, int OUTK, bool BACKWARD, bool STAMP>
+// NSLOT > 0: static shape, the number of weight slabs (Mid4Plan::st_total); 0: runtime extents
+template <int NL, int ACT_T, int OUTK, bool BACKWARD, bool STAMP, int NSLOT>
 __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     const int ACT = (ACT_T >= 0) ? ACT_T : p.inner_act;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -233,60 +236,110 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     GNN_STAMP4(0);
 
     // ---- phase 0: everything this block reads from memory, issued before anything waits ----
-    {   // A_1 rows and expected rows
-        const int q1 = m.ld[1] / 4, qy = m.ld[Lm] / 4;
-        for (int e = t; e < 4 * q1; e += NT_) {
-            const int mr = e / q1, q = e - mr * q1;
-            *reinterpret_cast<float4 *>(smem + m.off_act[1] + mr * (m.ld[1] + 4) + q * 4) =
-                *reinterpret_cast<const float4 *>(p.act[1] + (size_t)(row0 + mr) * m.ld[1] + q * 4);
-        }
-        if (p.Y) {
-            for (int e = NT_ - 1 - t; e < 4 * qy; e += NT_) { // the LAST threads: both loads fly together
-                const int mr = e / qy, q = e - mr * qy;
-                *reinterpret_cast<float4 *>(smem + m.off_y + mr * m.ld[Lm] + q * 4) =
-                    *reinterpret_cast<const float4 *>(p.Y + (size_t)(row0 + mr) * p.ldy + q * 4);
-            }
-        }
-    }
-    // weight images of every middle layer as ONE index space of float4s, all loads in flight at
-    // once; the start is rotated by the block's slot on its XCD
+    // A_1 rows and expected rows: one float4 per thread (4*ld/4 <= 1024 floats4 since kr <= 1024),
+    // held in registers until the weight loads are in flight too -- written `lds = global` the
+    // compiler waits for the load before it issues anything else
+    const int q1 = m.ld[1] / 4, qy = m.ld[Lm] / 4;
+    const bool a1_on = t < 4 * q1, y_on = p.Y != nullptr && NT_ - 1 - t < 4 * qy; // Y: the LAST threads
+    const int a1_r = t / q1, a1_q = t - a1_r * q1, y_e = NT_ - 1 - t, y_r = y_e / qy, y_q = y_e - y_r * qy;
+    // (lanes without an element re-read element 0 and never store it)
+    f32x4 a1v = *reinterpret_cast<const f32x4 *>(p.act[1] + (a1_on ? (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4 : (size_t)0));
+    f32x4 yv = *reinterpret_cast<const f32x4 *>((p.Y ? p.Y : p.act[1]) + (y_on ? (size_t)(row0 + y_r) * p.ldy + y_q * 4 : (size_t)0));
+    // Weight images. Layer j is walked in slabs of rpt rows x c4 float4s with thread -> (r0, c) fixed
+    // inside the slab: a slab then costs each thread ONE add for its LDS address and none for the
+    // global one (wave-uniform slab base + per-thread offset), where a flat index space over all
+    // layers cost ~25 VALU instructions per float4 -- and with 16 waves per CU every instruction of
+    // the stream is 16 issue cycles, which made staging issue-bound (2 us of the kernel).
+    // The four blocks that share an XCD start at different quarters of the slab sequence.
     {
-        const int total = m.w_total4;
-        const int rot = (int)(((long)total * ((blockIdx.x >> 3) & 3)) >> 2);
-        constexpr int MAXF = 10;
-        for (int base = 0; base < total; base += MAXF * NT_) {
-            float4 v[MAXF];
-            int dsto[MAXF];
+        const int q = (blockIdx.x >> 3) & 3; // wave-uniform
+        if constexpr (NSLOT > 0) {
+            // static shape: every load of every layer in flight before the first LDS write
+            f32x4 v[NSLOT];
 #pragma unroll
-            for (int i = 0; i < MAXF; i++) {
-                int idx = base + i * NT_ + t;
-                const bool in = idx < total;
-                idx += rot;
-                if (idx >= total) idx -= total;
-                // which layer's image: resolved with compile-time layer numbers only (an array
-                // indexed by a runtime layer would become a dependent memory lookup); the selects
-                // pick an address, the load itself has ONE site so v[] stays in registers
-                const float *src = p.W[1];
-                int dst = -1;
+            for (int j = 1; j < MAX_LAYERS - 1; j++) {
+                if (j < Lm) {
+                    const int c4 = m.kr[j + 1] >> 2, rpt = m.st_rpt[j], trips = m.st_trips[j];
+                    const int r0 = t / c4, c = t - r0 * c4;
+                    const unsigned goff = (unsigned)(r0 * m.ld[j + 1] + 4 * c);
+                    const int first = (trips * q) >> 2;
 #pragma unroll
-                for (int j = 1; j < MAX_LAYERS - 1; j++) {
-                    if (j < Lm) {
-                        const int c4 = m.kr[j + 1] >> 2;
-                        const int rel = idx - m.w_begin4[j];
-                        const int row = (int)(((unsigned long long)(unsigned)rel * m.w_inv_c4[j]) >> 32);
-                        const int col = (rel - row * c4) * 4;
-                        const bool here = in && rel >= 0 && rel < m.kr[j] * c4;
-                        src = here ? p.W[j] + (size_t)row * m.ld[j + 1] + col : src;
-                        dst = here ? m.off_w[j] + row * m.lw[j] + col : dst;
+                    for (int i = 0; i < NSLOT; i++) {
+                        if (i < trips) {
+                            int tr = i + first;
+                            tr = tr >= trips ? tr - trips : tr;
+                            const int rs = tr * rpt;
+                            const bool ok = r0 < rpt && r0 + rs < m.kr[j];
+                            // unconditional: lanes without a row re-read the image's first float4 and
+                            // never store it (a load under `if` gets sunk next to its store, serialising)
+                            v[m.st_begin[j] + i] = *reinterpret_cast<const f32x4 *>(p.W[j] + (ok ? (unsigned)(rs * m.ld[j + 1]) + goff : 0u));
+                        }
                     }
                 }
-                dsto[i] = dst;
-                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (dst >= 0) v[i] = *reinterpret_cast<const float4 *>(src);
             }
+            // pin every load above this point: left alone, the compiler sinks each load next to its
+            // (conditional) LDS store and the stream degenerates to load - wait - store per slab
+            asm volatile("" : "+v"(a1v), "+v"(yv));
 #pragma unroll
-            for (int i = 0; i < MAXF; i++)
-                if (dsto[i] >= 0) *reinterpret_cast<float4 *>(smem + dsto[i]) = v[i];
+            for (int i = 0; i < NSLOT; i++) asm volatile("" : "+v"(v[i]));
+            if (a1_on) *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
+            if (y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv;
+#pragma unroll
+            for (int j = 1; j < MAX_LAYERS - 1; j++) {
+                if (j < Lm) {
+                    const int c4 = m.kr[j + 1] >> 2, rpt = m.st_rpt[j], trips = m.st_trips[j];
+                    const int r0 = t / c4, c = t - r0 * c4;
+                    float *dst = smem + m.off_w[j] + r0 * m.lw[j] + 4 * c;
+                    const int first = (trips * q) >> 2;
+#pragma unroll
+                    for (int i = 0; i < NSLOT; i++) {
+                        if (i < trips) {
+                            int tr = i + first;
+                            tr = tr >= trips ? tr - trips : tr;
+                            const int rs = tr * rpt;
+                            if (r0 < rpt && r0 + rs < m.kr[j]) *reinterpret_cast<f32x4 *>(dst + rs * m.lw[j]) = v[m.st_begin[j] + i];
+                        }
+                    }
+                }
+            }
+        } else {
+            // runtime extents: layer by layer, up to MAXF slabs in flight
+            constexpr int MAXF = 10;
+#pragma unroll
+            for (int j = 1; j < MAX_LAYERS - 1; j++) {
+                if (j < Lm) {
+                    const int c4 = m.kr[j + 1] >> 2, rpt = m.st_rpt[j], trips = m.st_trips[j];
+                    const int r0 = (int)(((unsigned)t * m.st_inv_c4[j]) >> 22), c = t - r0 * c4;
+                    const unsigned goff = (unsigned)(r0 * m.ld[j + 1] + 4 * c);
+                    float *dst = smem + m.off_w[j] + r0 * m.lw[j] + 4 * c;
+                    const int first = (trips * q) >> 2;
+                    for (int tb = 0; tb < trips; tb += MAXF) {
+                        f32x4 v[MAXF];
+#pragma unroll
+                        for (int i = 0; i < MAXF; i++) {
+                            int tr = tb + i + first;
+                            tr = tr >= trips ? tr - trips : tr;
+                            const int rs = tr * rpt;
+                            const bool ok = tb + i < trips && r0 < rpt && r0 + rs < m.kr[j];
+                            v[i] = *reinterpret_cast<const f32x4 *>(p.W[j] + (ok ? (unsigned)(rs * m.ld[j + 1]) + goff : 0u));
+                        }
+#pragma unroll
+                        for (int i = 0; i < MAXF; i++) asm volatile("" : "+v"(v[i])); // pin the loads (see above)
+                        if (j == 1 && tb == 0) { // the first weight loads are in flight: now the rows
+                            asm volatile("" : "+v"(a1v), "+v"(yv));
+                            if (a1_on) *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
+                            if (y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv;
+                        }
+#pragma unroll
+                        for (int i = 0; i < MAXF; i++) {
+                            int tr = tb + i + first;
+                            tr = tr >= trips ? tr - trips : tr;
+                            const int rs = tr * rpt;
+                            if (tb + i < trips && r0 < rpt && r0 + rs < m.kr[j]) *reinterpret_cast<f32x4 *>(dst + rs * m.lw[j]) = v[i];
+                        }
+                    }
+                }
+            }
         }
     }
     __syncthreads();
@@ -426,9 +479,9 @@ __global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
         // a LOCAL constexpr object: every member access with a compile-time index folds to an
         // immediate (a namespace-scope constant would be loaded from memory)
         constexpr Mid4Plan m = SH::make();
-        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP>(m, p);
+        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, m.st_total>(m, p);
     } else {
-        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP>(p.plan, p);
+        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, 0>(p.plan, p);
     }
 }
 
