@@ -187,23 +187,25 @@ __device__ __forceinline__ void rowblock_product(const float *A_img, int lda, co
     } else {
         wp = Wimg + n0 + lane;
     }
-    // U groups of 4 k per trip: every LDS read of the trip is issued before the first MFMA waits
+    // U groups of 4 k per trip: every LDS read of the trip is issued before the first MFMA waits.
+    // Full trips carry no tail masks and the last 0..U-1 groups run one by one: the kernel is
+    // issue-bound (16 waves: every instruction of the stream costs 16 SIMD cycles), and masking a
+    // partial trip cost 4 selects per group in EVERY trip.
     constexpr int U = 4;
-    for (int kb = k4_begin; kb < k4_end; kb += U) { // bounds are wave-uniform
+    auto read_group = [&](int k4, f32x4 &a, f32x4 &b) {
+        a = *reinterpret_cast<const f32x4 *>(arow + 4 * k4);
+        if (TRANS) {
+            b = *reinterpret_cast<const f32x4 *>(wp + 4 * k4);
+        } else {
+            const float *w = wp + (4 * k4) * ldw;
+            b = (f32x4){w[0], w[ldw], w[2 * ldw], w[3 * ldw]};
+        }
+    };
+    int kb = k4_begin; // bounds are wave-uniform
+    for (; kb + U <= k4_end; kb += U) {
         f32x4 a[U], b[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const bool in = kb + u < k4_end;
-            const int k4 = in ? kb + u : k4_end - 1; // tail: re-read the last group with weight 0
-            a[u] = *reinterpret_cast<const f32x4 *>(arow + 4 * k4);
-            if (TRANS) {
-                b[u] = *reinterpret_cast<const f32x4 *>(wp + 4 * k4);
-            } else {
-                const float *w = wp + (4 * k4) * ldw;
-                b[u] = (f32x4){w[0], w[ldw], w[2 * ldw], w[3 * ldw]};
-            }
-            if (!in) a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        for (int u = 0; u < U; u++) read_group(kb + u, a[u], b[u]);
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (u & 1) {
@@ -214,6 +216,12 @@ __device__ __forceinline__ void rowblock_product(const float *A_img, int lda, co
                 for (int j = 0; j < 4; j++) acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u][j], b[u][j], acc0, 0, 0, 0);
             }
         }
+    }
+    for (; kb < k4_end; kb++) {
+        f32x4 a, b;
+        read_group(kb, a, b);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j], b[j], acc0, 0, 0, 0);
     }
     const f32x4 acc = acc0 + acc1;
 #pragma unroll
