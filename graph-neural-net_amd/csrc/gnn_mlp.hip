@@ -454,8 +454,8 @@ void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float
     for (int l = 0; l < g.n_layers; l++) g.layer[l].G = h->G + h->w_off[l];
     g.K = pad_up(B);
     g.step_over_b = step_over_b; g.momentum = momentum;
-    if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<true>, dim3(h->grad_tiles), dim3(256), 0, g);
-    else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<false>, dim3(h->grad_tiles), dim3(256), 0, g);
+    if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<true>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);
+    else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<false>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);
 }
 
 // Nets whose middle weights exceed LDS: per-layer GEMMs for the middle, and per CALL which of the two

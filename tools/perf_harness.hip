@@ -61,8 +61,8 @@ int main(int argc, char **argv) {
     };
     auto k_first = [&]() { hipLaunchKernelGGL((fwd_first_kernel<8>), dim3(f.tiling.blocks()), dim3(512), 0, s, f); };
     auto k_first16 = [&]() { hipLaunchKernelGGL((fwd_first_kernel<16>), dim3(f.tiling.blocks()), dim3(1024), 0, s, f); };
-    auto k_grad = [&]() { hipLaunchKernelGGL((grad_update_kernel<true>), dim3(tiles), dim3(256), 0, s, g); };
-    auto k_grad_nf = [&]() { hipLaunchKernelGGL((grad_update_kernel<false>), dim3(tiles), dim3(256), 0, s, g); };
+    auto k_grad = [&]() { hipLaunchKernelGGL((grad_update_kernel<true>), dim3(tiles), dim3(GRAD_THREADS), 0, s, g); };
+    auto k_grad_nf = [&]() { hipLaunchKernelGGL((grad_update_kernel<false>), dim3(tiles), dim3(GRAD_THREADS), 0, s, g); };
     time_it("fwd_first<8>", 500, k_first);
     time_it("fwd_first<16>", 500, k_first16);
     time_it("fwd_first<8,ACT=leaky>", 500, [&]() { hipLaunchKernelGGL((fwd_first_kernel<8, false, 0>), dim3(f.tiling.blocks()), dim3(512), 0, s, f); });
@@ -94,7 +94,7 @@ int main(int argc, char **argv) {
         printf("fwd_first stamps: kernel span %llu cycles;", t1 - t0);
         for (int w : {0, 1, 75, 150}) printf(" wg%d: start+%llu loads+mfma=%llu red=%llu epi=%llu |", w, hs[w*8]-t0, hs[w*8+1]-hs[w*8], hs[w*8+2]-hs[w*8+1], hs[w*8+3]-hs[w*8+2]);
         printf("\n");
-        hipLaunchKernelGGL((grad_update_kernel<true, true>), dim3(tiles), dim3(256), 0, s, g);
+        hipLaunchKernelGGL((grad_update_kernel<true, true>), dim3(tiles), dim3(GRAD_THREADS), 0, s, g);
         CK(hipStreamSynchronize(s));
         hs.resize(tiles * 8);
         CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
