@@ -44,6 +44,7 @@ struct Mid4Plan {
     int ks_bwd[MAX_LAYERS];  // K splits of the product giving delta_l (l = 1..L-2)
     // staging of weight image l: slabs of st_rpt[l] rows x c4 = kr[l+1]/4 float4s, one float4 per thread
     int st_rpt[MAX_LAYERS], st_trips[MAX_LAYERS], st_begin[MAX_LAYERS], st_total; // slabs per layer / first slot / all
+    unsigned inv_n4[MAX_LAYERS];    // ceil(2^22 / (ld[l]/4)): epilogue thread -> row = (t * inv) >> 22 (t < 1024, ld <= 1024)
     unsigned st_inv_c4[MAX_LAYERS]; // ceil(2^22 / c4): thread -> slab row = (t * inv) >> 22 (exact for t < 1024, c4 <= 256)
     int lds_floats;          // total dynamic LDS, floats
     bool ok;
@@ -62,6 +63,7 @@ __host__ __device__ constexpr Mid4Plan make_mid4_plan(const int *dims, int L) {
         m.ld[l] = (dims[l] + PAD - 1) / PAD * PAD;
         m.kr[l] = (dims[l] + 3) / 4 * 4;
     }
+    for (int l = 0; l < L; l++) m.inv_n4[l] = ((1u << 22) + m.ld[l] / 4 - 1) / (m.ld[l] / 4);
     int off = 0;
     for (int l = 1; l < Lm; l++) {
         int lw4 = m.kr[l + 1] / 4 + 1;
@@ -353,8 +355,7 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     __syncthreads();
     GNN_STAMP4(1);
 
-    const int rr = t >> 8, rc = t & 255; // epilogue thread -> (row, column + 256*i)
-    const bool live_row = row0 + rr < p.B;
+    constexpr bool IS_STATIC = NSLOT > 0;
 
     // ---- forward: layers 2 .. L-1 (SCE:172-194) ----
 #pragma unroll
@@ -368,22 +369,23 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                                     smem + m.off_scratch + ks * 4 * gw, gw, lane);
         }
         __syncthreads();
-        const bool last = (l == Lm);
-        float *img = smem + (last ? m.off_logits : m.off_act[l]);
-        for (int n = rc; n < N; n += 256) {
-            float v = 0.f;
-            if (n < m.kr[l])
-                for (int ks = 0; ks < KS; ks++) v += smem[m.off_scratch + (ks * 4 + rr) * gw + n];
-            const bool live = live_row && n < m.d[l];
-            if (last) {
-                img[rr * (N + 4) + n] = live ? v : 0.f;
-            } else {
-                const float a = live ? act_fn(ACT, v) : 0.f;
-                img[rr * (N + 4) + n] = a;
-                p.act[l][(size_t)(row0 + rr) * N + n] = a;
+        if (l < Lm) {
+            // K parts summed, f applied: one float4 per thread (4 rows x ld/4 <= 1024 float4s); the
+            // logits of the last layer are summed by the output wave itself, below
+            const int n4 = N >> 2;
+            const int er = IS_STATIC ? t / n4 : (int)(((unsigned)t * m.inv_n4[l]) >> 22), n = 4 * (t - er * n4);
+            if (t < 4 * n4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < m.kr[l])
+                    for (int ks = 0; ks < KS; ks++) v += *reinterpret_cast<const f32x4 *>(smem + m.off_scratch + (ks * 4 + er) * gw + n);
+                const bool lrow = row0 + er < p.B;
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = (lrow && n + j < m.d[l]) ? act_fn(ACT, v[j]) : 0.f;
+                *reinterpret_cast<f32x4 *>(smem + m.off_act[l] + er * (N + 4) + n) = v;
+                *reinterpret_cast<f32x4 *>(p.act[l] + (size_t)(row0 + er) * N + n) = v;
             }
+            __syncthreads();
         }
-        __syncthreads();
         GNN_STAMP4(4 + l);
     }
     GNN_STAMP4(2);
@@ -394,7 +396,16 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
         const int mr = lane >> 4, c0 = lane & 15;
         const int row = row0 + mr;
         const bool lrow = row < p.B;
-        const float *z = smem + m.off_logits + mr * (N + 4);
+        float *z = smem + m.off_logits + mr * (N + 4);
+        {   // logits = sum of the K parts of the last product; every lane reads back only what it wrote
+            const int G = (m.kr[Lm] + 63) / 64, gw = G * 64, KS = m.ks_fwd[Lm];
+            for (int c = c0; c < N; c += 16) {
+                float v = 0.f;
+                if (c < m.kr[Lm])
+                    for (int ks = 0; ks < KS; ks++) v += smem[m.off_scratch + (ks * 4 + mr) * gw + c];
+                z[c] = (lrow && c < nt) ? v : 0.f;
+            }
+        }
         const float *y = smem + m.off_y + mr * N;
         float *dimg = smem + m.off_dl[Lm] + mr * (N + 4);
         float mx = -__builtin_inff(), lsum = 0.f, nan_flag = 0.f; // MT:166-168 NaN rule, see output_layer_kernel
@@ -463,16 +474,20 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                                    smem + m.off_scratch + ks * 4 * gw, gw, lane);
         }
         __syncthreads();
-        const float *aimg = smem + m.off_act[l] + rr * (N + 4);
-        float *dimg = smem + m.off_dl[l] + rr * (N + 4);
-        for (int n = rc; n < N; n += 256) {
-            float v = 0.f;
-            if (n < NR)
-                for (int ks = 0; ks < KS; ks++) v += smem[m.off_scratch + (ks * 4 + rr) * gw + n];
-            const bool live = live_row && n < m.d[l];
-            const float dd = live ? v * act_prime_from_a(ACT, aimg[n]) : 0.f;
-            if (l > 1) dimg[n] = dd;
-            p.delta[l][(size_t)(row0 + rr) * N + n] = dd;
+        {
+            const int n4 = N >> 2;
+            const int er = IS_STATIC ? t / n4 : (int)(((unsigned)t * m.inv_n4[l]) >> 22), n = 4 * (t - er * n4);
+            if (t < 4 * n4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < NR)
+                    for (int ks = 0; ks < KS; ks++) v += *reinterpret_cast<const f32x4 *>(smem + m.off_scratch + (ks * 4 + er) * gw + n);
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(smem + m.off_act[l] + er * (N + 4) + n);
+                const bool lrow = row0 + er < p.B;
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = (lrow && n + j < m.d[l]) ? v[j] * act_prime_from_a(ACT, a[j]) : 0.f;
+                if (l > 1) *reinterpret_cast<f32x4 *>(smem + m.off_dl[l] + er * (N + 4) + n) = v;
+                *reinterpret_cast<f32x4 *>(p.delta[l] + (size_t)(row0 + er) * N + n) = v;
+            }
         }
         __syncthreads();
         GNN_STAMP4(10 + l);
