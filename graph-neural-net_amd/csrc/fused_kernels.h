@@ -59,6 +59,12 @@ __host__ inline XcdTiling make_xcd_tiling(int tiles_m, int tiles_n) {
     do {                                                                                      \
         if (STAMP && threadIdx.x == 0) (ptr)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+// s_memtime counts per-CU clocks with unrelated origins; the 100 MHz real-time counter is shared by
+// the whole device and is what block-to-block spans are measured with (slots 4 and 5)
+#define GNN_STAMP_REAL(ptr, i)                                                                \
+    do {                                                                                      \
+        if (STAMP && threadIdx.x == 0) (ptr)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 // ------------------------------------------------------------------------------------------
 // fwd_first_kernel: C[M x N] = epi(A[M x K] . W[K x N]), A k-contiguous, W n-contiguous.
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(NW * 64) void fwd_first_kernel(FwdFirstParams p) {
     const float *wcol = p.W + (size_t)(4 * fq) * p.ldw + n0 + fr;
 
     GNN_STAMP_AT(p.stamps, 0);
+    GNN_STAMP_REAL(p.stamps, 4);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int cb = c_begin; cb < c_end; cb += MAXC) {
         float4 a[MAXC];
@@ -152,6 +159,7 @@ __global__ __launch_bounds__(NW * 64) void fwd_first_kernel(FwdFirstParams p) {
         *reinterpret_cast<float4 *>(p.C + (size_t)(m0 + m) * p.ldc + n0 + q * 4) = o;
     }
     GNN_STAMP_AT(p.stamps, 3);
+    GNN_STAMP_REAL(p.stamps, 5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void grad_update_kernel(GradParams p)
     const bool e_ok = t < 256 && (m0 + er < L.M) && (n0 + eq * 4 < L.N);
     const size_t e_off = (size_t)(m0 + er) * L.ldd + n0 + eq * 4;
     GNN_STAMP_AT(p.stamps, 0);
+    GNN_STAMP_REAL(p.stamps, 4);
     // W / V rows first: their latency hides under the GEMM
     float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f), v_old = w_old;
     if (FUSED && e_ok) {
@@ -278,6 +287,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void grad_update_kernel(GradParams p)
         }
     }
     GNN_STAMP_AT(p.stamps, 3);
+    GNN_STAMP_REAL(p.stamps, 5);
 }
 
 } // namespace gnn

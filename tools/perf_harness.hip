@@ -10,6 +10,18 @@ using namespace gnn;
 using SS = StaticShape<784, 300, 100, 10>;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
+
+// block-to-block spans on the device-wide 100 MHz real-time counter (slots 4 = start, 5 = end)
+static void spans(const std::vector<unsigned long long> &hs, int blocks, const char *name) {
+    unsigned long long t0 = ~0ull, t1 = 0, s1 = 0, e0 = ~0ull;
+    for (int w = 0; w < blocks; w++) {
+        if (!hs[w * 8 + 4] || !hs[w * 8 + 5]) continue;
+        t0 = std::min(t0, hs[w * 8 + 4]); t1 = std::max(t1, hs[w * 8 + 5]); s1 = std::max(s1, hs[w * 8 + 4]); e0 = std::min(e0, hs[w * 8 + 5]);
+    }
+    printf("%s: first block start -> last block end %.2f us; last block starts %.2f us after the first; first block ends after %.2f us\n", name,
+           (t1 - t0) / 100.0, (s1 - t0) / 100.0, (e0 - t0) / 100.0);
+}
+
 int main(int argc, char **argv) {
     const int L = 4, dims[4] = {784, 300, 100, 10};
     int B = argc > 1 ? atoi(argv[1]) : 128;
@@ -85,23 +97,25 @@ int main(int argc, char **argv) {
         for (int w : {0, 1, 80, 150}) printf(" wg%d: loads+mfma=%llu red=%llu epi=%llu |", w, hs[w*8+1]-hs[w*8], hs[w*8+2]-hs[w*8+1], hs[w*8+3]-hs[w*8+2]);
         printf("\n");
         }
+        CK(hipMemsetAsync(stamps, 0, 4096 * 8, s));
         hipLaunchKernelGGL((fwd_first_kernel<8, true>), dim3(f.tiling.blocks()), dim3(512), 0, s, f);
         CK(hipStreamSynchronize(s));
         std::vector<unsigned long long> hs(f.tiling.blocks() * 8);
         CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull, t1 = 0;
-        for (int w = 0; w < 0; w++) { t0 = std::min(t0, hs[w * 8]); t1 = std::max(t1, hs[w * 8 + 3]); }
-        printf("fwd_first stamps: kernel span %llu cycles;", t1 - t0);
-        for (int w : {0, 1, 75, 150}) printf(" wg%d: start+%llu loads+mfma=%llu red=%llu epi=%llu |", w, hs[w*8]-t0, hs[w*8+1]-hs[w*8], hs[w*8+2]-hs[w*8+1], hs[w*8+3]-hs[w*8+2]);
+        spans(hs, f.tiling.blocks(), "fwd_first");
+        printf("fwd_first stamps:");
+        for (int w : {0, 1, 75, 150}) printf(" wg%d: loads+mfma=%llu red=%llu epi=%llu |", w, hs[w*8+1]-hs[w*8], hs[w*8+2]-hs[w*8+1], hs[w*8+3]-hs[w*8+2]);
         printf("\n");
+        CK(hipMemsetAsync(stamps, 0, 4096 * 8, s));
         hipLaunchKernelGGL((grad_update_kernel<true, true>), dim3(tiles), dim3(GRAD_THREADS), 0, s, g);
         CK(hipStreamSynchronize(s));
         hs.resize(tiles * 8);
         CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
         t0 = ~0ull; t1 = 0;
-        for (int w = 0; w < 0; w++) { t0 = std::min(t0, hs[w * 8]); t1 = std::max(t1, hs[w * 8 + 3]); }
-        printf("grad_update stamps: kernel span %llu cycles;", t1 - t0);
-        for (int w : {0, 1, 128, 249, 281, 329}) printf(" wg%d: start+%llu load=%llu mfma=%llu epi=%llu |", w, hs[w*8]-t0, hs[w*8+1]-hs[w*8], hs[w*8+2]-hs[w*8+1], hs[w*8+3]-hs[w*8+2]);
+        spans(hs, tiles, "grad_update");
+        printf("grad_update stamps:");
+        for (int w : {0, 1, 128, 249, 281, 329}) printf(" wg%d: load=%llu mfma=%llu epi=%llu |", w, hs[w*8+1]-hs[w*8], hs[w*8+2]-hs[w*8+1], hs[w*8+3]-hs[w*8+2]);
         printf("\n");
     }
     {
