@@ -84,7 +84,7 @@ struct FwdFirstParams {
 
 template <int NW, bool STAMP = false, int ACT = -1>
 __global__ __launch_bounds__(NW * 64) void fwd_first_kernel(FwdFirstParams p) {
-    constexpr int MAXC = 8; // chunks whose loads are in flight at once (8 * (4+4) VGPRs)
+    constexpr int MAXC = NW >= 8 ? 8 : NW >= 4 ? 13 : NW == 3 ? 17 : 25; // chunks whose loads are in flight at once (MAXC * (4+4) VGPRs)
     constexpr int RLD = 20; // row stride of a partial tile in LDS
     __shared__ __attribute__((aligned(16))) float red[NW * 16 * RLD];
     int tm, tn;

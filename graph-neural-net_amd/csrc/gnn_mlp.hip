@@ -402,13 +402,28 @@ void launch_fwd_first(gnn_mlp *h, const float *a0, int B) {
     f.tiling = make_xcd_tiling(f.M / 16, f.N / 16);
     // activation as a template argument: a runtime switch in the epilogue costs ~1000 cycles of
     // instruction fetch on branch targets (measured 1400-2100 vs 650 cycles)
-    const dim3 fg(f.tiling.blocks()), fb(FIRST_NW * 64);
-    switch (h->inner_act) {
-    case 0: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 0>, fg, fb, 0, f); break;
-    case 1: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 1>, fg, fb, 0, f); break;
-    case 2: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 2>, fg, fb, 0, f); break;
-    case 3: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 3>, fg, fb, 0, f); break;
-    default: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 4>, fg, fb, 0, f); break;
+    // 4 waves when each can keep its whole K share in flight at once (<= 13 chunks of 16: K <= 832),
+    // else 8: waves are launched at ~2 100 per us chip-wide, so at this size halving the wave count
+    // is worth more than the shorter per-wave chain (4.2 vs 4.6 us at 784x300, B = 128)
+    const dim3 fg(f.tiling.blocks());
+    if (f.K / 16 <= 4 * 13) {
+        const dim3 fb(4 * 64);
+        switch (h->inner_act) {
+        case 0: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<4, false, 0>, fg, fb, 0, f); break;
+        case 1: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<4, false, 1>, fg, fb, 0, f); break;
+        case 2: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<4, false, 2>, fg, fb, 0, f); break;
+        case 3: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<4, false, 3>, fg, fb, 0, f); break;
+        default: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<4, false, 4>, fg, fb, 0, f); break;
+        }
+    } else {
+        const dim3 fb(FIRST_NW * 64);
+        switch (h->inner_act) {
+        case 0: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 0>, fg, fb, 0, f); break;
+        case 1: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 1>, fg, fb, 0, f); break;
+        case 2: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 2>, fg, fb, 0, f); break;
+        case 3: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 3>, fg, fb, 0, f); break;
+        default: launch_timed(h, GNN_K_FWD_GEMM0, fwd_first_kernel<FIRST_NW, false, 4>, fg, fb, 0, f); break;
+        }
     }
 }
 

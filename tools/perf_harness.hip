@@ -77,6 +77,9 @@ int main(int argc, char **argv) {
     auto k_grad_nf = [&]() { hipLaunchKernelGGL((grad_update_kernel<false>), dim3(tiles), dim3(GRAD_THREADS), 0, s, g); };
     time_it("fwd_first<8>", 500, k_first);
     time_it("fwd_first<16>", 500, k_first16);
+    time_it("fwd_first<4,ACT=leaky>", 500, [&]() { hipLaunchKernelGGL((fwd_first_kernel<4, false, 0>), dim3(f.tiling.blocks()), dim3(256), 0, s, f); });
+    time_it("fwd_first<3,ACT=leaky>", 500, [&]() { hipLaunchKernelGGL((fwd_first_kernel<3, false, 0>), dim3(f.tiling.blocks()), dim3(192), 0, s, f); });
+    time_it("fwd_first<2,ACT=leaky>", 500, [&]() { hipLaunchKernelGGL((fwd_first_kernel<2, false, 0>), dim3(f.tiling.blocks()), dim3(128), 0, s, f); });
     time_it("fwd_first<8,ACT=leaky>", 500, [&]() { hipLaunchKernelGGL((fwd_first_kernel<8, false, 0>), dim3(f.tiling.blocks()), dim3(512), 0, s, f); });
     auto k_mid4r = [&]() { hipLaunchKernelGGL((middle4_kernel<RuntimeShape<4>, 0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
     auto k_mid4 = [&]() { hipLaunchKernelGGL((middle4_kernel<SS, 0, 0, true, false>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); };
