@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="data-parallel path: eager steps, no hipGraph replay")
     ap.add_argument("--dp-path", action="store_true",
                     help="run the data-parallel code path (compute -> all_reduce -> update) even at N=1")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control flow on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,6 +99,8 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.dp_path:
@@ -104,7 +109,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     K, W = args.steps, args.warmup
     n_batches = 64
@@ -128,21 +136,23 @@ def main():
         side = torch.cuda.Stream()
         stepper = dp.DataParallelStep(dp.HipEngine(net, torch, stream=side), dist, always_reduce=args.dp_path)
         graphed = None
-        if not args.no_graph:
+        if not args.no_graph and args.backend == "nccl":  # (a gloo collective cannot be captured)
             try:  # one pass over the 64 resident batches as ONE graph launch
                 graphed = dp.GraphedSteps(stepper, torch, side, [b * BATCH for b in range(n_batches)],
                                           BATCH, STEP, MOMENTUM)
             except Exception as e:  # capture of the collective not available: eager steps
                 if rank == 0:
-                    print("graph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
+                    print("graph capture failed (%s: %s); running eager" % (type(e).__name__, str(e).splitlines()[0]), file=sys.stderr)
                 graphed = None
+                side = torch.cuda.Stream()       # the stream of a failed capture may stay unusable
+                stepper.engine.rebind_stream(side)
 
-        def run(first_batch, n):
+        def run(first_batch, n, eager=False):
             s = 0
             with torch.cuda.stream(side):
                 while s < n:
                     b = (first_batch + s) % n_batches
-                    if graphed is not None and b == 0 and n - s >= n_batches:
+                    if graphed is not None and not eager and b == 0 and n - s >= n_batches:
                         graphed.replay()
                         s += n_batches
                     else:
@@ -163,11 +173,18 @@ def main():
     # ---- dominant-kernel roofline: HIP events on the kernel's own stream, over the same step loop
     roofline = None
     cpu = None
+    # The kernel-timing pass steps the net again. On the data-parallel path a step contains a
+    # collective, so EVERY rank takes part (eagerly: kernels inside a replayed graph are not
+    # timed); only rank 0 records and reports.
+    nt = min(K, 1000) if dist is None else min(K, 256)
     if rank == 0:
         net.timing_enable(True)
-        nt = min(K, 1000)
+    if dist is None:
         run(W + K, nt)
-        net.synchronize()
+    else:
+        run(W + K, nt, eager=True)
+    barrier()
+    if rank == 0:
         fwd_us, fwd_n = net.timing_read(0)
         grad_us, grad_n = net.timing_read(1)
         mid_us, mid_n = net.timing_read(3)
@@ -179,25 +196,29 @@ def main():
         #   fwd_first : 2*B*d0*d1 FLOP; reads A_0 (B*d0) + W_0 (d0*d1), writes A_1 (B*d1)
         #   middle    : 2*B*2*(P - d0 d1) FLOP; reads W_1.. once per use (fwd + bwd), A_1, Y; writes A_2.., delta_1..
         #   grad      : 2*B*P FLOP; reads A_l, delta_{l+1} for every layer and W, V (2P); writes W, V (2P)
-        hidden = sum(DIMS[1:-1])
+        #   (data-parallel path: the same kernel stores G instead -- P written, W and V untouched;
+        #    the update is sgd_momentum_kernel after the all-reduce)
+        dp = dist is not None
+        grad_name = "grad_update(all layers, 784x300xB + ..., stores G; update after the all-reduce)" if dp \
+            else "grad_update(all layers, 784x300xB + ...)"
         kernels = {
             "fwd_first(128x784x300)": (fwd_us, 2.0 * BATCH * DIMS[0] * DIMS[1],
                                        e4 * (BATCH * DIMS[0] + DIMS[0] * DIMS[1] + BATCH * DIMS[1])),
             "middle(fwd L2.. + softmax + bwd-data)": (mid_us, 2.0 * BATCH * 2 * P_mid,
                                                       e4 * (2 * P_mid + BATCH * (DIMS[1] + 2 * DIMS[-1] + 2 * sum(DIMS[1:])))),
-            "grad_update(all layers, 784x300xB + ...)": (grad_us, 2.0 * BATCH * P_all,
-                                                         e4 * (4 * P_all + BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:])))),
+            grad_name: (grad_us, 2.0 * BATCH * P_all,
+                        e4 * ((1 if dp else 4) * P_all + BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:])))),
         }
         step_us = dt / K * 1e6
         # roofline kernel: the one that moves the most bytes and FLOPs -- every layer's G = A^T.delta
         # with the momentum update fused.  Its arithmetic intensity (13 FLOP/B) is below the f32
         # ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B), so the bound that applies is HBM.
-        name = "grad_update(all layers, 784x300xB + ...)"
+        name = grad_name
         us, flop, nbytes = kernels[name]
         ach = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic("grad_update_kernel"),
+                    "traffic": None if dp else pmc_traffic("grad_update_kernel<true"),
                     "avg_launch_us": round(us, 3), "launches": grad_n,
                     "algorithmic_bytes_per_launch": nbytes, "flop_per_launch": flop,
                     "arithmetic_intensity_flop_per_byte": round(flop / nbytes, 2),

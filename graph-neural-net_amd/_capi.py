@@ -61,6 +61,7 @@ SYMBOLS = [
     ("gnn_mlp_apply_update", C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
     ("gnn_mlp_synchronize", C.c_int, [_H]),
     ("gnn_mlp_advance_time", C.c_int, [_H, C.c_int]),
+    ("gnn_mlp_recover_stream", C.c_int, [_H]),
     ("gnn_mlp_specialize", C.c_int, [_H]),
     ("gnn_mlp_specialization", C.c_int, [_H]),
     ("gnn_mlp_timing_enable", C.c_int, [_H, C.c_int]),

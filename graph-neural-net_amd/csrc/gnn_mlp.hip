@@ -1165,7 +1165,10 @@ int gnn_mlp_bind_grad_buffer(gnn_mlp_t *h, void *dev_ptr, int64_t n_elems) {
 
 int gnn_mlp_set_stream(gnn_mlp_t *h, void *hip_stream) {
     TRY(check_handle(h));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+    if (!capturing) HIP_TRY(hipStreamSynchronize(h->stream)); // (a capturing stream cannot be waited on)
+    else (void)hipGetLastError();
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
     return GNN_OK;
 }
@@ -1197,6 +1200,22 @@ int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentu
 int gnn_mlp_advance_time(gnn_mlp_t *h, int steps) {
     if (!h || h->time + steps < 0) return fail(GNN_ERR_BAD_ARG, "bad argument");
     h->time += steps; // negative: steps that were only CAPTURED (enqueued into a graph, not run)
+    return GNN_OK;
+}
+
+int gnn_mlp_recover_stream(gnn_mlp_t *h) {
+    TRY(check_handle(h));
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(h->stream, &g); // an invalidated capture returns an error and no graph
+        if (g) (void)hipGraphDestroy(g);
+        st = hipStreamCaptureStatusNone;
+        // a stream the runtime keeps in the invalidated state is given up: the handle falls back to
+        // its own stream and the caller binds a fresh one with gnn_mlp_set_stream
+        if (hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) h->stream = h->own_stream;
+    }
+    for (int i = 0; i < 8 && hipGetLastError() != hipSuccess; i++) {}
     return GNN_OK;
 }
 

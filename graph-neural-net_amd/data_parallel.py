@@ -40,6 +40,12 @@ class HipEngine:
         net.set_stream(self.stream.cuda_stream)
         net.bind_grad_buffer(self.grad_tensor.data_ptr(), self.grad_tensor.numel())
 
+    def rebind_stream(self, stream):
+        """Move the net's kernels to another torch stream (after a capture that left the old one
+        unusable)."""
+        self.stream = stream
+        self.net.set_stream(stream.cuda_stream)
+
     def compute_gradient_range(self, first, B):
         self.net.compute_gradient_range(first, B)
 
@@ -96,10 +102,20 @@ class GraphedSteps:
             for f in firsts:
                 stepper.step(f, B_local, step, momentum)
         stream.synchronize()
-        with torch.cuda.graph(self.graph, stream=stream):
-            for f in firsts:
-                stepper.step(f, B_local, step, momentum)
-        stepper.engine.net.advance_time(-self.n)  # the capture pass enqueued, it did not run
+        net = stepper.engine.net
+        t_before = net.time
+        try:
+            with torch.cuda.graph(self.graph, stream=stream):
+                for f in firsts:
+                    stepper.step(f, B_local, step, momentum)
+        except Exception:
+            # a collective that cannot be captured invalidates the capture: leave capture mode, drop
+            # the sticky HIP error and the steps that were only enqueued, so that the caller can go
+            # on with eager steps (bench.py does)
+            net.recover_stream()
+            net.advance_time(t_before - net.time)
+            raise
+        net.advance_time(-self.n)                 # the capture pass enqueued, it did not run
         self.eager_steps = self.n                 # steps really executed by the warm pass
 
     def replay(self):

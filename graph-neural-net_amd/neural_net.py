@@ -258,6 +258,10 @@ class NeuralNet:
     def advance_time(self, steps):
         _capi.check(self._lib.gnn_mlp_advance_time(self._h, int(steps)))
 
+    def recover_stream(self):
+        """After a failed stream capture: leave capture mode, drop the sticky HIP error."""
+        _capi.check(self._lib.gnn_mlp_recover_stream(self._h))
+
     # -- shape specialisation -----------------------------------------------------------------
     def specialize(self):
         """Instantiate the fused path's kernels for this net's layer sizes (hiprtc)."""

@@ -194,6 +194,12 @@ int gnn_mlp_synchronize(gnn_mlp_t *h);
  * it reports the replayed steps here (and takes back, with a negative count, the steps that
  * were only captured, not executed). */
 int gnn_mlp_advance_time(gnn_mlp_t *h, int steps);
+/* After a stream capture that FAILED (e.g. a collective that cannot be captured invalidated it):
+ * ends a capture still open on the handle's stream, discards its graph and clears the sticky HIP
+ * error of the calling thread, so that eager calls work again; if the runtime keeps the stream
+ * in the invalidated state the handle returns to its own stream and the caller binds a fresh one
+ * with gnn_mlp_set_stream. No reference counterpart. */
+int gnn_mlp_recover_stream(gnn_mlp_t *h);
 
 /* ---- shape specialisation ---------------------------------------------------------------------
  * The per-row-block kernel of the fused small-net path is a template over the net's shape; with
