@@ -162,7 +162,7 @@ def main():
     run(0, W)
     barrier()
     t0 = time.perf_counter()
-    run(W, K)
+    run(0 if dist is not None else W, K)  # data parallel: start on a graph boundary (64 resident batches)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -182,7 +182,7 @@ def main():
     if dist is None:
         run(W + K, nt)
     else:
-        run(W + K, nt, eager=True)
+        run(K, nt, eager=True)
     barrier()
     if rank == 0:
         fwd_us, fwd_n = net.timing_read(0)
