@@ -223,6 +223,13 @@ def main():
                     "algorithmic_bytes_per_launch": nbytes, "flop_per_launch": flop,
                     "arithmetic_intensity_flop_per_byte": round(flop / nbytes, 2),
                     "mfma_frac": round(flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if us > 0 else None,
+                    # SURVEY 8d, whole step: 6P - 2 d0 d1 FLOP per sample; bytes = weights (P + (P - d0 d1) + P + 5P)
+                    # + activations B (d0 + 4 sum_{l>=1} d_l), 4 B each
+                    "whole_step": {"flop": (6 * P_all - 2 * DIMS[0] * DIMS[1]) * BATCH,
+                                   "algorithmic_bytes": e4 * (8 * P_all - DIMS[0] * DIMS[1] + BATCH * (DIMS[0] + 4 * sum(DIMS[1:]))),
+                                   "us": round(step_us, 3),
+                                   "mfma_frac": round((6 * P_all - 2 * DIMS[0] * DIMS[1]) * BATCH / (step_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                   "hbm_frac": round(e4 * (8 * P_all - DIMS[0] * DIMS[1] + BATCH * (DIMS[0] + 4 * sum(DIMS[1:]))) / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
                     "other": {k: {"avg_us": round(v[0], 3), "flop": v[1], "algorithmic_bytes": v[2],
                                   "tflops": round(v[1] / (v[0] * 1e-6) / 1e12, 3) if v[0] > 0 else None,
                                   "gbs": round(v[2] / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else None,

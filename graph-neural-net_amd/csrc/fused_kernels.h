@@ -185,14 +185,15 @@ struct GradParams {
     unsigned long long *stamps; // STAMP builds only
 };
 
-constexpr int GRAD_THREADS = 512;
-template <bool FUSED, bool STAMP = false>
-__global__ __launch_bounds__(GRAD_THREADS) void grad_update_kernel(GradParams p) {
+constexpr int GRAD_THREADS = 512; // default: 8 waves; 256 (4 waves, no K halves) for grids of > ~1000 tiles
+template <bool FUSED, bool STAMP = false, int NTHR = GRAD_THREADS>
+__global__ __launch_bounds__(NTHR) void grad_update_kernel(GradParams p) {
+    constexpr int KSPLIT = NTHR / 256;
     constexpr int KC = 128, LDS_LD = 48; // row stride = 16 (mod 32) floats
     constexpr int CLD = 36;
     __shared__ __attribute__((aligned(16))) float As[KC * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Ds[KC * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Cs[2 * 32 * CLD];
+    __shared__ __attribute__((aligned(16))) float Cs[KSPLIT * 32 * CLD];
     // 8 waves: 2x2 MFMA tiles x 2 halves of every K chunk.  The f32 MFMA work of a tile is fixed
     // (128 instructions of 32 cycles over 4 SIMDs), but with one wave per SIMD its LDS reads and
     // the dependent accumulator chain are exposed; two waves per SIMD cover each other.
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(GRAD_THREADS) void grad_update_kernel(GradParams p)
         if (k0) __syncthreads();
         // 32 floats (8 float4) per row per operand; thread -> (row = idx / 8, q = idx % 8)
 #pragma unroll
-        for (int i = 0; i < KC * 8 / GRAD_THREADS; i++) {
-            const int idx = t + i * GRAD_THREADS, k = idx >> 3, q = idx & 7;
+        for (int i = 0; i < KC * 8 / NTHR; i++) {
+            const int idx = t + i * NTHR, k = idx >> 3, q = idx & 7;
             float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vd = va;
             if (k < kc) {
                 if (m0 + q * 4 < L.M) va = *reinterpret_cast<const float4 *>(L.A + (size_t)(k0 + k) * L.lda + m0 + q * 4);
@@ -258,9 +259,9 @@ __global__ __launch_bounds__(GRAD_THREADS) void grad_update_kernel(GradParams p)
         };
         if (kc == KC) { // this wave's half of the chunk
 #pragma unroll
-            for (int kk = 0; kk < KC / 2; kk += 32) trip(kh * (KC / 2) + kk);
+            for (int kk = 0; kk < KC / KSPLIT; kk += 32) trip(kh * (KC / KSPLIT) + kk);
         } else {        // kc is a multiple of 16: 4-k steps dealt alternately to the two halves
-            for (int kk = 4 * kh; kk < kc; kk += 8)
+            for (int kk = 4 * kh; kk < kc; kk += 4 * KSPLIT)
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * LDS_LD], dp[kk * LDS_LD], acc0, 0, 0, 0);
         }
     }
@@ -270,9 +271,11 @@ __global__ __launch_bounds__(GRAD_THREADS) void grad_update_kernel(GradParams p)
     for (int r = 0; r < 4; r++) Cs[(kh * 32 + wm * 16 + fq * 4 + r) * CLD + wn * 16 + fr] = acc[r];
     __syncthreads();
     if (e_ok) {
-        const float4 g0 = *reinterpret_cast<const float4 *>(&Cs[er * CLD + eq * 4]);
-        const float4 g1 = *reinterpret_cast<const float4 *>(&Cs[(32 + er) * CLD + eq * 4]);
-        const float4 gsum = make_float4(g0.x + g1.x, g0.y + g1.y, g0.z + g1.z, g0.w + g1.w);
+        float4 gsum = *reinterpret_cast<const float4 *>(&Cs[er * CLD + eq * 4]);
+        if (KSPLIT == 2) {
+            const float4 g1 = *reinterpret_cast<const float4 *>(&Cs[(32 + er) * CLD + eq * 4]);
+            gsum = make_float4(gsum.x + g1.x, gsum.y + g1.y, gsum.z + g1.z, gsum.w + g1.w);
+        }
         if (FUSED) { // ((step*G)/B) + (momentum*prev), SCE:333
             float4 adj, wn_;
             adj.x = p.step_over_b * gsum.x + p.momentum * v_old.x;

@@ -177,6 +177,8 @@ void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
     }
 }
 
+constexpr int FIRST_NW = 8;  // waves per fwd_first_kernel workgroup (K split in-LDS)
+
 // ---- forward (SCE:164-198): a0 = f(x) rows, B live rows ------------------------------------
 // leaves act[1..L-2], logits; the output kernel is launched by the caller via run_output.
 void forward(gnn_mlp *h, const float *a0, int B, int first_l = 1) {
@@ -193,6 +195,19 @@ void forward(gnn_mlp *h, const float *a0, int B, int first_l = 1) {
             p.C = h->act[l]; p.ldc = h->ld[l];
             launch_gemm<true, false, EPI_ACT>(h, l == 1 ? GNN_K_FWD_GEMM0 : -1, p);
             in = h->act[l];
+        } else if (h->dtype == GNN_DTYPE_F32 && p.N <= 32 && p.K >= 128) {
+            // narrow logits (10 classes -> one or two 16-column tiles): a tiled GEMM would run a handful of
+            // workgroups down the whole K; one 16x16 tile per workgroup with K split over its 8 waves
+            // instead (784-1024^3-10 at 256 rows: 15.3 -> ~5 us)
+            FwdFirstParams f{};
+            f.A = p.A; f.lda = p.lda;
+            f.W = p.B; f.ldw = p.ldb;
+            f.C = h->logits; f.ldc = h->ld[l];
+            f.M = p.M; f.N = p.N; f.K = p.K;
+            f.m_true = p.m_true; f.n_true = p.n_true;
+            f.act = 0; f.apply_act = 0;
+            f.tiling = make_xcd_tiling(f.M / 16, f.N / 16);
+            launch_timed(h, -1, fwd_first_kernel<FIRST_NW, false, -1>, dim3(f.tiling.blocks()), dim3(FIRST_NW * 64), 0, f);
         } else {
             p.C = h->logits; p.ldc = h->ld[l];
             launch_gemm<true, false, EPI_STORE>(h, l == 1 ? GNN_K_FWD_GEMM0 : -1, p);
@@ -254,7 +269,6 @@ void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_
 }
 
 // ---- fused small-net path ---------------------------------------------------------------------
-constexpr int FIRST_NW = 8;  // waves per fwd_first_kernel workgroup (K split in-LDS)
 
 void plan_mid4(gnn_mlp *h);
 
@@ -469,8 +483,14 @@ void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float
     for (int l = 0; l < g.n_layers; l++) g.layer[l].G = h->G + h->w_off[l];
     g.K = pad_up(B);
     g.step_over_b = step_over_b; g.momentum = momentum;
-    if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<true>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);
-    else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<false>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);
+    // waves are launched at ~2 100 per us chip-wide: big grids take the 4-wave form
+    if (h->grad_tiles > 1024) {
+        if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<true, false, 256>, dim3(h->grad_tiles), dim3(256), 0, g);
+        else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<false, false, 256>, dim3(h->grad_tiles), dim3(256), 0, g);
+    } else {
+        if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<true>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);
+        else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<false>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);
+    }
 }
 
 // Nets whose middle weights exceed LDS: per-layer GEMMs for the middle, and per CALL which of the two
