@@ -72,8 +72,8 @@ struct gnn_mlp {
     bool fused = false;
     GradParams grad{};
     int grad_tiles = 0;
-    bool mid_generic = false; // middle weights fit neither LDS plan: per-layer GEMMs between fwd_first and grad_update
-    bool mid4 = false;        // middle4_kernel (LDS-resident weights) instead of middle_kernel
+    bool mid_generic = false; // middle weights exceed LDS: per-layer GEMMs, fwd_first / grad_update chosen per call (hybrid_choice)
+    bool mid4 = false;        // middle4_kernel: every middle weight matrix resident in LDS
     Mid4Params mid4p{};
     size_t mid4_lds_bytes = 0;
     const void *mid4_fn[2] = {nullptr, nullptr}; // [backward]

@@ -337,7 +337,7 @@ def test_graph_replayed_steps_equal_eager(gnn):
 
 
 @pytest.mark.parametrize("dims,B,inner", [
-    ([784, 512, 256, 10], 64, LEAKY),          # middle weights exceed LDS -> 16-row middle_kernel
+    ([784, 512, 256, 10], 64, LEAKY),          # middle weights exceed LDS -> per-layer GEMMs between the one-launch kernels
     ([100, 64, 48, 32, 10], 40, SIGMOID),      # L = 5, middle4 with runtime shape
     ([60, 50, 40, 30, 20, 10], 33, TANH),      # L = 6
     ([784, 300, 100, 10], 1000, LEAKY),        # large batch (250 row blocks)
