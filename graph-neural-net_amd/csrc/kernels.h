@@ -172,18 +172,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Fragment rows are INTERLEAVED: MFMA tile i of this wave holds the rows base + TM*rho + i
+    // (rho = the tile's own row index 0..15), tile j the columns base + TN*gamma + j.  Any assignment of
+    // rows to tiles is a valid GEMM, and with this one a lane's TM (TN) operand values for a k sit
+    // next to each other in the [k][m] LDS image: ONE b128 / b64 read per operand per k step instead
+    // of TM (TN) b32 reads, and the epilogue stores TN consecutive columns per lane (16 B for TN = 4).
     const int fr = lane & 15, fq = lane >> 4;
-    const int a_base = fq * LDAS + wm * (TM * 16) + fr;
-    const int b_base = fq * LDBS + wn * (TN * 16) + fr;
+    const int a_base = fq * LDAS + wm * (TM * 16) + fr * TM;
+    const int b_base = fq * LDBS + wn * (TN * 16) + fr * TN;
+    typedef float vec_a __attribute__((ext_vector_type(TM == 1 ? 2 : TM))); // (a 1-vector is not a type; b32 read below)
+    typedef float vec_b __attribute__((ext_vector_type(TN == 1 ? 2 : TN)));
 
     auto multiply = [&]() {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             float a[TM], b[TN];
+            if constexpr (TM == 1) {
+                a[0] = As[kk * LDAS + a_base];
+            } else {
+                const vec_a va = *reinterpret_cast<const vec_a *>(&As[kk * LDAS + a_base]);
 #pragma unroll
-            for (int i = 0; i < TM; i++) a[i] = As[kk * LDAS + a_base + i * 16];
+                for (int i = 0; i < TM; i++) a[i] = va[i];
+            }
+            if constexpr (TN == 1) {
+                b[0] = Bs[kk * LDBS + b_base];
+            } else {
+                const vec_b vb = *reinterpret_cast<const vec_b *>(&Bs[kk * LDBS + b_base]);
 #pragma unroll
-            for (int j = 0; j < TN; j++) b[j] = Bs[kk * LDBS + b_base + j * 16];
+                for (int j = 0; j < TN; j++) b[j] = vb[j];
+            }
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -219,33 +236,57 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
     }
 
-    // epilogue: C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+    // epilogue: C/D map of the 16x16 MFMA: tile column gamma = lane&15, tile row rho = (lane>>4)*4 + reg;
+    // with the interleaving above, row = base + TM*rho + i and columns base + TN*gamma + (0..TN-1)
+    const int n = n0 + wn * (TN * 16) + fr * TN; // this lane's TN consecutive columns (all inside or all outside N)
 #pragma unroll
     for (int i = 0; i < TM; i++) {
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = n0 + wn * (TN * 16) + j * 16 + fr;
+        for (int r = 0; r < 4; r++) {
+            const int m = m0 + wm * (TM * 16) + (fq * 4 + r) * TM + i;
+            if (m < p.M && n < p.N) {
+                const size_t off = (size_t)m * p.ldc + n;
+                float v[TN], aux[TN], vold[TN], wold[TN];
+                if (EPI == EPI_DACT) {
+                    if constexpr (TN == 1) aux[0] = p.aux[(size_t)m * p.ldaux + n];
+                    else {
+                        const vec_b t_ = *reinterpret_cast<const vec_b *>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int m = m0 + wm * (TM * 16) + i * 16 + fq * 4 + r;
-                if (m < p.M && n < p.N) {
-                    const bool live = (m < p.m_true) && (n < p.n_true);
-                    float v = acc[i][j][r];
-                    const size_t off = (size_t)m * p.ldc + n;
-                    if (EPI == EPI_STORE) {
-                        p.C[off] = live ? v : 0.f;
-                    } else if (EPI == EPI_ACT) {
-                        p.C[off] = live ? act_fn(p.act, v) : 0.f;
-                    } else if (EPI == EPI_DACT) {
-                        const float a = p.aux[(size_t)m * p.ldaux + n];
-                        p.C[off] = live ? v * act_prime_from_a(p.act, a) : 0.f;
-                    } else { // EPI_SGD: ((step*G)/B) + (momentum*prev), SCE:333
-                        if (live) {
-                            const float adj = p.step_over_b * v + p.momentum * p.V[off];
-                            p.W[off] -= adj;
-                            p.V[off] = adj;
-                        }
+                        for (int j = 0; j < TN; j++) aux[j] = t_[j];
                     }
+                }
+                if (EPI == EPI_SGD) {
+                    if constexpr (TN == 1) { vold[0] = p.V[off]; wold[0] = p.W[off]; }
+                    else {
+                        const vec_b tv = *reinterpret_cast<const vec_b *>(p.V + off), tw = *reinterpret_cast<const vec_b *>(p.W + off);
+#pragma unroll
+                        for (int j = 0; j < TN; j++) { vold[j] = tv[j]; wold[j] = tw[j]; }
+                    }
+                }
+                float out0[TN], out1[TN]; // out0: C (or W), out1: V
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const bool live = (m < p.m_true) && (n + j < p.n_true);
+                    v[j] = acc[i][j][r];
+                    if (EPI == EPI_STORE) out0[j] = live ? v[j] : 0.f;
+                    else if (EPI == EPI_ACT) out0[j] = live ? act_fn(p.act, v[j]) : 0.f;
+                    else if (EPI == EPI_DACT) out0[j] = live ? v[j] * act_prime_from_a(p.act, aux[j]) : 0.f;
+                    else { // EPI_SGD: ((step*G)/B) + (momentum*prev), SCE:333; padding elements stay as they are (zeros)
+                        const float adj = p.step_over_b * v[j] + p.momentum * vold[j];
+                        out0[j] = live ? wold[j] - adj : wold[j];
+                        out1[j] = live ? adj : vold[j];
+                    }
+                }
+                float *dst0 = (EPI == EPI_SGD) ? p.W + off : p.C + off;
+                if constexpr (TN == 1) {
+                    dst0[0] = out0[0];
+                    if (EPI == EPI_SGD) p.V[off] = out1[0];
+                } else {
+                    vec_b o0, o1;
+#pragma unroll
+                    for (int j = 0; j < TN; j++) { o0[j] = out0[j]; if (EPI == EPI_SGD) o1[j] = out1[j]; }
+                    *reinterpret_cast<vec_b *>(dst0) = o0;
+                    if (EPI == EPI_SGD) *reinterpret_cast<vec_b *>(p.V + off) = o1;
                 }
             }
         }
