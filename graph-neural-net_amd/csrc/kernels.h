@@ -337,7 +337,65 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
     // at index 0 is sticky (label 0) while a NaN elsewhere is never selected.  With softmax any
     // NaN logit makes EVERY probability NaN, i.e. label 0.
     bool has_nan = false;
-    if (p.out_kind == 0) {
+    constexpr int CV = 16; // a row of up to 64*CV logits is held in registers: ONE round trip to memory
+    if (p.out_kind == 0 && p.n_pad <= 64 * CV) {
+        // (a row read three times with dependent loads -- max, sum, probabilities -- cost 19.6 us at 512 x 1024)
+        const int nv = (p.n_pad + 63) / 64; // wave-uniform
+        float zc[CV], yc[CV];
+#pragma unroll
+        for (int i = 0; i < CV; i++) {
+            const int c = lane + 64 * i;
+            zc[i] = 0.f; yc[i] = 0.f;
+            if (i < nv && c < p.n_pad) {
+                zc[i] = z[c];
+                if (y) yc[i] = y[c];
+            }
+        }
+        float mx = -__builtin_inff();
+        int best = -1;
+#pragma unroll
+        for (int i = 0; i < CV; i++) {
+            const int c = lane + 64 * i;
+            if (i < nv && c < p.n_true) {
+                has_nan |= (zc[i] != zc[i]);
+                if (zc[i] >= mx) { mx = zc[i]; best = c; } // ascending c within a lane: `>=` keeps the highest
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { // larger value wins, equal values -> higher index (MT:166-168)
+            const float ov = __shfl_xor(mx, o);
+            const int ob = __shfl_xor(best, o);
+            if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
+        }
+        float s = 0.f, e[CV];
+#pragma unroll
+        for (int i = 0; i < CV; i++) {
+            e[i] = 0.f;
+            if (i < nv && lane + 64 * i < p.n_true) { e[i] = __expf(zc[i] - mx); s += e[i]; }
+        }
+        s = wave_sum(s);
+        const float inv = 1.f / s;
+        const float lse = mx + __logf(s);
+        float l = 0.f;
+#pragma unroll
+        for (int i = 0; i < CV; i++) {
+            const int c = lane + 64 * i;
+            if (i < nv && c < p.n_pad) {
+                const bool live = live_row && c < p.n_true;
+                const float pr = live ? e[i] * inv : 0.f;
+                const float yy = live ? yc[i] : 0.f;
+                if (p.prob) p.prob[(size_t)row * p.ldp + c] = pr;
+                if (p.delta) p.delta[(size_t)row * p.ldd + c] = live ? pr - yy : 0.f;
+                if (live && yy != 0.f) l += yy * (lse - zc[i]); // -y ln p
+            }
+        }
+        l = wave_sum(l);
+        if (__any(has_nan)) best = 0;
+        if (lane == 0) {
+            if (p.loss) p.loss[row] = live_row ? l : 0.f;
+            if (p.label) p.label[row] = live_row ? best : -1;
+        }
+    } else if (p.out_kind == 0) { // wider rows: three passes over memory
         float mx = -__builtin_inff();
         int best = -1;
         for (int c = lane; c < p.n_true; c += 64) {
