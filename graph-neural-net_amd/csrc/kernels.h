@@ -86,7 +86,7 @@ struct GemmParams {
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
-    constexpr int BK = (BM == 32) ? 64 : 32;    // 32x32 tiles do 8 MFMAs per wave per 32 k: twice the K per barrier pair
+    constexpr int BK = (BM <= 64) ? 64 : 32;    // small tiles do few MFMAs per wave per 32 k: twice the K per barrier pair
     constexpr int TM = BM / 32, TN = BN / 32;   // 16x16 MFMA tiles per wave (waves are 2 x 2)
     constexpr int LDAS = BM + 16, LDBS = BN + 16; // row stride = 16 (mod 32) floats: lanes 0-15 / 16-31 hit disjoint banks
     __shared__ __attribute__((aligned(16))) float As[BK * LDAS];
