@@ -80,6 +80,7 @@ struct FwdFirstParams {
     int act, apply_act;
     XcdTiling tiling;
     unsigned long long *stamps; // STAMP builds only
+    const int32_t *row_idx;     // optional: row m of A is dataset row row_idx[m] (sampled batches, NNT:143-158)
 };
 
 template <int NW, bool STAMP = false, int ACT = -1>
@@ -95,7 +96,9 @@ __global__ __launch_bounds__(NW * 64) void fwd_first_kernel(FwdFirstParams p) {
     const int k16 = p.K / 16;
     const int c_begin = (int)((long)wave * k16 / NW), c_end = (int)((long)(wave + 1) * k16 / NW);
 
-    const float *arow = p.A + (size_t)(m0 + fr) * p.lda + 4 * fq;
+    int a_row = m0 + fr;
+    if (p.row_idx) a_row = a_row < p.m_true ? p.row_idx[a_row] : 0; // rows past the batch: any valid row, masked at the end
+    const float *arow = p.A + (size_t)a_row * p.lda + 4 * fq;
     const float *wcol = p.W + (size_t)(4 * fq) * p.ldw + n0 + fr;
 
     GNN_STAMP_AT(p.stamps, 0);
@@ -183,6 +186,8 @@ struct GradParams {
     int K;                     // padded batch rows
     float step_over_b, momentum;
     unsigned long long *stamps; // STAMP builds only
+    const int32_t *row_idx;     // optional, layer 0 only: batch row k of A_0 is dataset row row_idx[k]
+    int k_true;                 // live batch rows (rows past them are zeros when row_idx is given)
 };
 
 constexpr int GRAD_THREADS = 512; // default: 8 waves; 256 (4 waves, no K halves) for grids of > ~1000 tiles
@@ -232,7 +237,13 @@ __global__ __launch_bounds__(NTHR) void grad_update_kernel(GradParams p) {
             const int idx = t + i * NTHR, k = idx >> 3, q = idx & 7;
             float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vd = va;
             if (k < kc) {
-                if (m0 + q * 4 < L.M) va = *reinterpret_cast<const float4 *>(L.A + (size_t)(k0 + k) * L.lda + m0 + q * 4);
+                size_t a_row = (size_t)(k0 + k);
+                bool a_live = true;
+                if (li == 0 && p.row_idx) { // sampled batch: the input rows are gathered here, not copied first
+                    a_live = k0 + k < p.k_true;
+                    a_row = a_live ? (size_t)p.row_idx[k0 + k] : 0;
+                }
+                if (a_live && m0 + q * 4 < L.M) va = *reinterpret_cast<const float4 *>(L.A + a_row * L.lda + m0 + q * 4);
                 if (n0 + q * 4 < L.N) vd = *reinterpret_cast<const float4 *>(L.D + (size_t)(k0 + k) * L.ldd + n0 + q * 4);
             }
             *reinterpret_cast<float4 *>(&As[k * LDS_LD + q * 4]) = va;

@@ -17,7 +17,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace gnn;
@@ -87,6 +90,8 @@ struct gnn_mlp {
     hipGraph_t tr_graph = nullptr;
     int64_t tr_first_batch = -1; int tr_B = 0; int64_t tr_nb = 0; double tr_step = 0, tr_mom = 0;
     const float *tr_dx = nullptr;
+
+    const int32_t *cur_idx = nullptr; // device row indices of the batch being stepped (fused path reads rows through them)
 
     bool timing = false;
     TimerClass timers[4];
@@ -413,6 +418,7 @@ void launch_fwd_first(gnn_mlp *h, const float *a0, int B) {
     f.M = B_pad; f.N = h->ld[1]; f.K = h->ld[0];
     f.m_true = B; f.n_true = h->dims[1];
     f.act = h->inner_act; f.apply_act = 1;
+    f.row_idx = h->cur_idx;
     f.tiling = make_xcd_tiling(f.M / 16, f.N / 16);
     // activation as a template argument: a runtime switch in the epilogue costs ~1000 cycles of
     // instruction fetch on branch targets (measured 1400-2100 vs 650 cycles)
@@ -452,6 +458,7 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
         m4.loss = want_loss ? h->lossv : nullptr;
         m4.label = want_label ? h->labels : nullptr;
         m4.B = B;
+        m4.row_idx = h->cur_idx;
         void *args[] = {&m4};
         // every padded row is processed: rows >= B become zeros
         const int bw = backward ? 1 : 0;
@@ -482,6 +489,7 @@ void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float
     g.layer[0].A = a0;
     for (int l = 0; l < g.n_layers; l++) g.layer[l].G = h->G + h->w_off[l];
     g.K = pad_up(B);
+    g.row_idx = h->cur_idx; g.k_true = B;
     g.step_over_b = step_over_b; g.momentum = momentum;
     // waves are launched at ~2 100 per us chip-wide: big grids take the 4-wave form
     if (h->grad_tiles > 1024) {
@@ -1135,6 +1143,14 @@ int gnn_sampler_sample(gnn_sampler_t *s, int batch, int32_t *out_idx, int *n_out
 
 static int step_on_device_indices(gnn_mlp *h, const int32_t *d_idx, int B, double step, double momentum) {
     const int B_pad = pad_up(B), Lm = h->L - 1;
+    if (h->mid4) {
+        // fused path: its three kernels read the sampled rows of the resident dataset through the
+        // index vector themselves (two gather launches cost 14 us of a 33-us step)
+        h->cur_idx = d_idx;
+        const int rc = step_on_rows(h, h->DX, h->DY, B, step, momentum);
+        h->cur_idx = nullptr;
+        return rc;
+    }
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * h->ld[0] / 4)), dim3(256), 0, h->stream,
                        h->DX, h->ld[0], d_idx, B, B_pad, h->act[0]);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * h->ld[Lm] / 4)), dim3(256), 0, h->stream,
@@ -1152,18 +1168,48 @@ int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int ba
     if (s->master != h->dataset_n) return fail(GNN_ERR_BAD_ARG, "sampler size differs from the dataset");
     if (batch >= s->master) return fail(GNN_ERR_BAD_ARG, "batchSize must be below the data size (NNT:63)");
     if (iterations >= 64) try_specialize(h);
+    // The exact epoch sampler is serial host work (~10 us per batch of 128: two Fenwick walks per
+    // draw) of the same order as a step on the GPU, so it runs AHEAD on a worker thread, chunk by
+    // chunk, while this thread uploads finished chunks and enqueues their steps.
+    const int chunk = 256;
+    const int n_chunks = (iterations + chunk - 1) / chunk;
     std::vector<int32_t> idx((size_t)iterations * batch);
     std::vector<int> cnt((size_t)iterations);
-    for (int i = 0; i < iterations; i++) TRY(gnn_sampler_sample(s, batch, idx.data() + (size_t)i * batch, &cnt[i]));
+    std::mutex mu;
+    std::condition_variable cv;
+    int ready = 0, sampler_rc = GNN_OK; // chunks sampled so far (guarded by mu)
+    std::string sampler_msg;
+    std::thread producer([&]() {
+        for (int c = 0; c < n_chunks; c++) {
+            int rc = GNN_OK;
+            const int i1 = std::min(iterations, (c + 1) * chunk);
+            for (int i = c * chunk; i < i1 && rc == GNN_OK; i++) rc = gnn_sampler_sample(s, batch, idx.data() + (size_t)i * batch, &cnt[i]);
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc != GNN_OK) { sampler_rc = rc; sampler_msg = gnn_mlp_last_error(); ready = n_chunks; cv.notify_all(); return; }
+            ready = c + 1;
+            cv.notify_all();
+        }
+    });
     int32_t *d_idx = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_idx, idx.size() * sizeof(int32_t)));
-    hipError_t e = hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
     int rc = GNN_OK;
-    if (e != hipSuccess) rc = fail(GNN_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
-    for (int i = 0; i < iterations && rc == GNN_OK; i++)
-        rc = step_on_device_indices(h, d_idx + (size_t)i * batch, cnt[i], step, momentum);
+    if (hipMalloc((void **)&d_idx, idx.size() * sizeof(int32_t)) != hipSuccess) rc = fail(GNN_ERR_HIP, "hipMalloc of the index buffer failed");
+    for (int c = 0; c < n_chunks && rc == GNN_OK; c++) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return ready > c; });
+            if (sampler_rc != GNN_OK) { rc = fail(sampler_rc, sampler_msg); break; }
+        }
+        const int i0 = c * chunk, i1 = std::min(iterations, i0 + chunk);
+        // (pageable hipMemcpyAsync returns once the host data has been consumed)
+        const hipError_t e = hipMemcpyAsync(d_idx + (size_t)i0 * batch, idx.data() + (size_t)i0 * batch,
+                                            (size_t)(i1 - i0) * batch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) { rc = fail(GNN_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); break; }
+        for (int i = i0; i < i1 && rc == GNN_OK; i++)
+            rc = step_on_device_indices(h, d_idx + (size_t)i * batch, cnt[i], step, momentum);
+    }
+    producer.join(); // (on an early exit the sampler still finishes its draws: its state stays well defined)
     (void)hipStreamSynchronize(h->stream); // idx (host) and d_idx are released below
-    (void)hipFree(d_idx);
+    if (d_idx) (void)hipFree(d_idx);
     return rc;
 }
 

@@ -119,6 +119,7 @@ struct Mid4Params {
     int B;
     int inner_act, last_act;     // inner_act is read only by kernels built with ACT = -1
     unsigned long long *stamps;  // STAMP builds only
+    const int32_t *row_idx;      // optional: expected row of batch row r is Y row row_idx[r] (sampled batches)
 };
 
 // NL > 0: the layer COUNT is a compile-time constant (extents stay kernel arguments), so the
@@ -254,7 +255,9 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     const int a1_r = t / q1, a1_q = t - a1_r * q1, y_e = NT_ - 1 - t, y_r = y_e / qy, y_q = y_e - y_r * qy;
     // (lanes without an element re-read element 0 and never store it)
     f32x4 a1v = *reinterpret_cast<const f32x4 *>(p.act[1] + (a1_on ? (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4 : (size_t)0));
-    f32x4 yv = *reinterpret_cast<const f32x4 *>((p.Y ? p.Y : p.act[1]) + (y_on ? (size_t)(row0 + y_r) * p.ldy + y_q * 4 : (size_t)0));
+    size_t y_row = (size_t)(row0 + y_r);
+    if (y_on && p.row_idx) y_row = row0 + y_r < p.B ? (size_t)p.row_idx[row0 + y_r] : 0; // rows past the batch are masked below
+    f32x4 yv = *reinterpret_cast<const f32x4 *>((p.Y ? p.Y : p.act[1]) + (y_on ? y_row * p.ldy + y_q * 4 : (size_t)0));
     // Weight images. Layer j is walked in slabs of rpt rows x c4 float4s with thread -> (r0, c) fixed
     // inside the slab: a slab then costs each thread ONE add for its LDS address and none for the
     // global one (wave-uniform slab base + per-thread offset), where a flat index space over all
