@@ -85,6 +85,12 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line: libraries that chat on fd 1 (RCCL prints a version banner there,
+    # gloo its connection report) are routed to stderr until the line is printed
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -237,7 +243,10 @@ def main():
         if dist is None and not args.no_cpu_baseline:
             cpu = cpu_baseline()
 
+    lockstep = None
     if dist is not None:
+        # every rank applied the same all-reduced gradient: the replicas must hold identical weights
+        lockstep = stepper.replicas_in_lockstep(torch, device="cuda" if args.backend == "nccl" else "cpu")
         dist.barrier()
         dist.destroy_process_group()
 
@@ -254,10 +263,13 @@ def main():
                                    "batch 128 per GPU (BASELINE configs[1])",
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                        "dp_mode": (None if dist is None else ("hipGraph replay of 64 steps" if graphed is not None else "eager")),
+                       "dp_replicas_identical": lockstep,
                        "step": STEP, "momentum": MOMENTUM, "inner_activation": "leaky_relu"},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)
 
 
