@@ -85,3 +85,38 @@ def test_checkpoint_round_trip(gnn, tmp_path):
     c = gnn.SoftmaxCrossEntropyNeuralNet([784, 100, 40, 10], max_batch=B)
     with pytest.raises(gnn.GnnError):
         c.load_checkpoint(tmp_path / "ck.bin")
+
+
+def test_train_sampled_ragged_batches_and_chunks(gnn, oracle_mod):
+    """gnn_mlp_train_sampled on the fused path reads the sampled rows through the index vector
+    inside its kernels (no gather pass) and samples ahead on a worker thread in chunks of 256
+    iterations: a batch size that is not a multiple of the 4-row blocks / 16-row padding, an epoch
+    that ends mid-batch, and a run longer than one chunk must equal index-by-index stepping
+    (bitwise) and the oracle driven by the oracle's own sampler."""
+    dims, N, B = [64, 40, 24, 10], 101, 27
+    rng = np.random.default_rng(5)
+    X = rng.random((N, dims[0])) * (rng.random((N, dims[0])) < 0.5)
+    lab = rng.integers(0, 10, N)
+    Y = np.eye(10)[lab]
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    ta = gnn.NeuralNetTrainer(X, Y, a)
+    iters = 300                                               # two sampler chunks (256 + 44), 80 epochs
+    ta.train(iters, 0.01, B, 0.9, False)
+    b.upload_dataset(X, Y)
+    smp = gnn.Sampler(N)
+    ref = oracle_mod.OracleNet(dims)
+    ref.set_alloc_per_sample(0)
+    osmp = oracle_mod.Sampler(N)
+    for i in range(iters):
+        idx = smp.sample(B)
+        b.gradient_step_indexed(idx, 0.01, 0.9, False)
+        if i < 40:
+            oidx = osmp.sample(B)
+            assert np.array_equal(np.asarray(idx), np.asarray(oidx))
+            ref.gradient_step(X[oidx], Y[oidx], 0.01, 0.9)
+            if i == 39:
+                assert np.abs(b.get_weights() - ref.get_weights()).max() <= 2e-6 * 40
+    assert a.time == iters == b.time
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    assert np.array_equal(a.get_momentum(), b.get_momentum())
