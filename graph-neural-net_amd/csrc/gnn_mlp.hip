@@ -1042,25 +1042,24 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
     return GNN_OK;
 }
 
-static int gather_batch(gnn_mlp *h, const int32_t *idx, int B) {
-    for (int i = 0; i < B; i++)
-        if (idx[i] < 0 || idx[i] >= h->dataset_n) return fail(GNN_ERR_BAD_ARG, "sample index out of range");
-    HIP_TRY(hipMemcpyAsync(h->idxbuf, idx, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+// inputs and expected rows of a sampled batch in ONE launch (nets off the fused path)
+static void launch_gather(gnn_mlp *h, const int32_t *d_idx, int B) {
     const int B_pad = pad_up(B), Lm = h->L - 1;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * h->ld[0] / 4)), dim3(256), 0, h->stream,
-                       h->DX, h->ld[0], h->idxbuf, B, B_pad, h->act[0]);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * h->ld[Lm] / 4)), dim3(256), 0, h->stream,
-                       h->DY, h->ld[Lm], h->idxbuf, B, B_pad, h->ybuf);
-    return GNN_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * (h->ld[0] + h->ld[Lm]) / 4)), dim3(256), 0, h->stream,
+                       h->DX, h->ld[0], h->act[0], h->DY, h->ld[Lm], h->ybuf, d_idx, B, B_pad);
 }
+
+static int step_on_device_indices(gnn_mlp *h, const int32_t *d_idx, int B, double step, double momentum);
 
 int gnn_mlp_gradient_step_indexed(gnn_mlp_t *h, const int32_t *idx, int B, double step, double momentum, int noise) {
     TRY(check_handle(h));
     if (!idx) return fail(GNN_ERR_BAD_ARG, "null index list");
     TRY(check_step_args(h, B, step, noise));
     if (!h->DX) return fail(GNN_ERR_STATE, "no dataset uploaded");
-    TRY(gather_batch(h, idx, B));
-    return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum);
+    for (int i = 0; i < B; i++)
+        if (idx[i] < 0 || idx[i] >= h->dataset_n) return fail(GNN_ERR_BAD_ARG, "sample index out of range");
+    HIP_TRY(hipMemcpyAsync(h->idxbuf, idx, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    return step_on_device_indices(h, h->idxbuf, B, step, momentum);
 }
 
 int gnn_mlp_loss_range(gnn_mlp_t *h, int64_t first, int B, double *loss_per_sample) {
@@ -1142,7 +1141,6 @@ int gnn_sampler_sample(gnn_sampler_t *s, int batch, int32_t *out_idx, int *n_out
 }
 
 static int step_on_device_indices(gnn_mlp *h, const int32_t *d_idx, int B, double step, double momentum) {
-    const int B_pad = pad_up(B), Lm = h->L - 1;
     if (h->mid4) {
         // fused path: its three kernels read the sampled rows of the resident dataset through the
         // index vector themselves (two gather launches cost 14 us of a 33-us step)
@@ -1151,10 +1149,7 @@ static int step_on_device_indices(gnn_mlp *h, const int32_t *d_idx, int B, doubl
         h->cur_idx = nullptr;
         return rc;
     }
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * h->ld[0] / 4)), dim3(256), 0, h->stream,
-                       h->DX, h->ld[0], d_idx, B, B_pad, h->act[0]);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B_pad * h->ld[Lm] / 4)), dim3(256), 0, h->stream,
-                       h->DY, h->ld[Lm], d_idx, B, B_pad, h->ybuf);
+    launch_gather(h, d_idx, B);
     return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum);
 }
 

@@ -529,17 +529,24 @@ __global__ __launch_bounds__(256) void onehot_u8_kernel(const uint8_t *__restric
 }
 
 // gather dataset rows by index (one NNT.sample draw, NNT:143-158) into a dense batch
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int ld,
-                                                         const int32_t *__restrict__ idx, int B, int B_pad,
-                                                         float *__restrict__ dst) {
-    const int ld4 = ld / 4;
-    const int64_t total = (int64_t)B_pad * ld4;
+// rows idx[0..B) of TWO row-aligned matrices (inputs and expected outputs) in one launch
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src_x, int ld_x, float *__restrict__ dst_x,
+                                                         const float *__restrict__ src_y, int ld_y, float *__restrict__ dst_y,
+                                                         const int32_t *__restrict__ idx, int B, int B_pad) {
+    const int x4 = ld_x / 4, y4 = ld_y / 4, row4 = x4 + y4;
+    const int64_t total = (int64_t)B_pad * row4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int r = (int)(i / ld4);
-        const int c = (int)(i - (int64_t)r * ld4);
+        const int r = (int)(i / row4);
+        const int c = (int)(i - (int64_t)r * row4);
+        const bool in_x = c < x4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < B) v = reinterpret_cast<const float4 *>(src + (size_t)idx[r] * ld)[c];
-        reinterpret_cast<float4 *>(dst)[i] = v;
+        if (r < B) {
+            const size_t row = (size_t)idx[r];
+            v = in_x ? reinterpret_cast<const float4 *>(src_x + row * ld_x)[c]
+                     : reinterpret_cast<const float4 *>(src_y + row * ld_y)[c - x4];
+        }
+        if (in_x) reinterpret_cast<float4 *>(dst_x + (size_t)r * ld_x)[c] = v;
+        else reinterpret_cast<float4 *>(dst_y + (size_t)r * ld_y)[c - x4] = v;
     }
 }
 
