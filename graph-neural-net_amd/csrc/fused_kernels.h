@@ -304,4 +304,124 @@ __global__ __launch_bounds__(NTHR) void grad_update_kernel(GradParams p) {
     GNN_STAMP_REAL(p.stamps, 5);
 }
 
+// ------------------------------------------------------------------------------------------
+// grad_update64_kernel: the same one-launch gradient (+ update) with 64x64 tiles, for nets whose
+// 32x32 grid runs to thousands of tiles: a 32x32 tile reads its two K x 32 panels for 1024 outputs,
+// a 64x64 tile two K x 64 panels for 4096 -- half the L2 traffic per output (784-1024^3-10 at 256
+// rows moved 210 MB through L2 per step with 32x32 tiles, ~6 TB/s, and was bound by it).
+// 8 waves = 2x2 sub-tiles of 32x32 (2x2 MFMA tiles each, rows/columns interleaved so that an operand
+// fragment is one ds_read_b64) x 2 halves of every 64-row K chunk; partial tiles meet in LDS.
+// ------------------------------------------------------------------------------------------
+template <bool FUSED>
+__global__ __launch_bounds__(512) void grad_update64_kernel(GradParams p) {
+    constexpr int T = 64, KC = 64, LD = T + 16, CLD = T + 4;
+    __shared__ __attribute__((aligned(16))) float sm[2 * KC * LD]; // A and D panels; later the two partial tiles
+    static_assert(2 * T * CLD <= 2 * KC * LD, "partial tiles reuse the operand panels");
+    float *As = sm, *Ds = sm + KC * LD;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fq = lane >> 4, wm = (wave >> 1) & 1, wn = wave & 1, kh = wave >> 2;
+
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_LAYERS; i++)
+        if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].block_begin) li = i;
+    const GradLayer &L = p.layer[li];
+    int tm, tn;
+    if (!L.tiling.tile_of(blockIdx.x - L.block_begin, tm, tn)) return;
+    const int m0 = tm * T, n0 = tn * T;
+
+    // this thread's two 16-B pieces of the output tile: rows er and er + 32, columns 4*eq .. 4*eq+3
+    const int er = t >> 4, eq = t & 15;
+    bool e_ok[2];
+    size_t e_off[2];
+    float4 w_old[2], v_old[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        e_ok[i] = (m0 + er + 32 * i < L.M) && (n0 + eq * 4 < L.N);
+        e_off[i] = (size_t)(m0 + er + 32 * i) * L.ldd + n0 + eq * 4;
+        w_old[i] = make_float4(0.f, 0.f, 0.f, 0.f); v_old[i] = w_old[i];
+        if (FUSED && e_ok[i]) { // W / V rows first: their latency hides under the GEMM
+            w_old[i] = *reinterpret_cast<const float4 *>(L.W + e_off[i]);
+            v_old[i] = *reinterpret_cast<const float4 *>(L.V + e_off[i]);
+        }
+    }
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += KC) {
+        const int kc = (p.K - k0 < KC) ? p.K - k0 : KC; // a multiple of 16
+        if (k0) __syncthreads();
+        // 64 floats (16 float4) per row per operand; thread -> (row = idx / 16, q = idx % 16)
+#pragma unroll
+        for (int i = 0; i < KC * 16 / 512; i++) {
+            const int idx = t + i * 512, k = idx >> 4, q = idx & 15;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vd = va;
+            if (k < kc) {
+                size_t a_row = (size_t)(k0 + k);
+                bool a_live = true;
+                if (li == 0 && p.row_idx) {
+                    a_live = k0 + k < p.k_true;
+                    a_row = a_live ? (size_t)p.row_idx[k0 + k] : 0;
+                }
+                if (a_live && m0 + q * 4 < L.M) va = *reinterpret_cast<const float4 *>(L.A + a_row * L.lda + m0 + q * 4);
+                if (n0 + q * 4 < L.N) vd = *reinterpret_cast<const float4 *>(L.D + (size_t)(k0 + k) * L.ldd + n0 + q * 4);
+            }
+            *reinterpret_cast<float4 *>(&As[k * LD + q * 4]) = va;
+            *reinterpret_cast<float4 *>(&Ds[k * LD + q * 4]) = vd;
+        }
+        __syncthreads();
+        // this wave's half of the chunk; MFMA tile i holds rows wm*32 + 2*rho + i, tile j columns wn*32 + 2*gamma + j
+        const float *ap = &As[fq * LD + wm * 32 + fr * 2];
+        const float *dp = &Ds[fq * LD + wn * 32 + fr * 2];
+        const int kk_end = (kh + 1) * (KC / 2) < kc ? (kh + 1) * (KC / 2) : kc;
+        for (int kk = kh * (KC / 2); kk < kk_end; kk += 16) { // kc, KC/2 are multiples of 16
+            f32x2 a[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a[u] = *reinterpret_cast<const f32x2 *>(ap + (kk + 4 * u) * LD);
+                d[u] = *reinterpret_cast<const f32x2 *>(dp + (kk + 4 * u) * LD);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], d[u][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads(); // the panels are free: partial tile of K half kh at sm[kh*T*CLD]
+    float *Cs = sm + kh * (T * CLD);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = wm * 32 + (fq * 4 + r) * 2 + i;
+            *reinterpret_cast<f32x2 *>(&Cs[row * CLD + wn * 32 + fr * 2]) = (f32x2){acc[i][0][r], acc[i][1][r]};
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (!e_ok[i]) continue;
+        const float4 g0 = *reinterpret_cast<const float4 *>(&sm[(er + 32 * i) * CLD + eq * 4]);
+        const float4 g1 = *reinterpret_cast<const float4 *>(&sm[T * CLD + (er + 32 * i) * CLD + eq * 4]);
+        const float4 gsum = make_float4(g0.x + g1.x, g0.y + g1.y, g0.z + g1.z, g0.w + g1.w);
+        if (FUSED) { // ((step*G)/B) + (momentum*prev), SCE:333
+            float4 adj, wn_;
+            adj.x = p.step_over_b * gsum.x + p.momentum * v_old[i].x;
+            adj.y = p.step_over_b * gsum.y + p.momentum * v_old[i].y;
+            adj.z = p.step_over_b * gsum.z + p.momentum * v_old[i].z;
+            adj.w = p.step_over_b * gsum.w + p.momentum * v_old[i].w;
+            wn_.x = w_old[i].x - adj.x; wn_.y = w_old[i].y - adj.y; wn_.z = w_old[i].z - adj.z; wn_.w = w_old[i].w - adj.w;
+            *reinterpret_cast<float4 *>(L.W + e_off[i]) = wn_;
+            *reinterpret_cast<float4 *>(L.V + e_off[i]) = adj;
+        } else {
+            *reinterpret_cast<float4 *>(L.G + e_off[i]) = gsum;
+        }
+    }
+}
+
 } // namespace gnn

@@ -75,6 +75,8 @@ struct gnn_mlp {
     bool fused = false;
     GradParams grad{};
     int grad_tiles = 0;
+    GradParams grad64{};      // the same layers cut into 64x64 tiles (grad_update64_kernel), used when grad_tiles is large
+    int grad_tiles64 = 0;
     bool mid_generic = false; // middle weights exceed LDS: per-layer GEMMs, fwd_first / grad_update chosen per call (hybrid_choice)
     bool mid4 = false;        // middle4_kernel: every middle weight matrix resident in LDS
     Mid4Params mid4p{};
@@ -304,6 +306,16 @@ void plan_fused(gnn_mlp *h) {
             tiles += gl.tiling.blocks();
         }
         h->grad_tiles = tiles;
+        GradParams &g64 = h->grad64;
+        g64 = g;
+        int tiles64 = 0;
+        for (int l = 0; l < L - 1; l++) {
+            GradLayer &gl = g64.layer[l];
+            gl.tiling = make_xcd_tiling((gl.M + 63) / 64, (gl.N + 63) / 64);
+            gl.block_begin = tiles64;
+            tiles64 += gl.tiling.blocks();
+        }
+        h->grad_tiles64 = tiles64;
     }
     // preferred: 4-row blocks with LDS-resident middle weights
     plan_mid4(h);
@@ -485,16 +497,17 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
 }
 
 void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_over_b, float momentum) {
-    GradParams g = h->grad;
+    // grids of thousands of 32x32 tiles are bound by L2 traffic: 64x64 tiles halve it
+    const bool big = h->grad_tiles > 1024;
+    GradParams g = big ? h->grad64 : h->grad;
     g.layer[0].A = a0;
     for (int l = 0; l < g.n_layers; l++) g.layer[l].G = h->G + h->w_off[l];
     g.K = pad_up(B);
     g.row_idx = h->cur_idx; g.k_true = B;
     g.step_over_b = step_over_b; g.momentum = momentum;
-    // waves are launched at ~2 100 per us chip-wide: big grids take the 4-wave form
-    if (h->grad_tiles > 1024) {
-        if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<true, false, 256>, dim3(h->grad_tiles), dim3(256), 0, g);
-        else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<false, false, 256>, dim3(h->grad_tiles), dim3(256), 0, g);
+    if (big) {
+        if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update64_kernel<true>, dim3(h->grad_tiles64), dim3(512), 0, g);
+        else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update64_kernel<false>, dim3(h->grad_tiles64), dim3(512), 0, g);
     } else {
         if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<true>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);
         else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<false>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);

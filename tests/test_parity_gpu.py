@@ -344,6 +344,7 @@ def test_graph_replayed_steps_equal_eager(gnn):
     ([300, 10], 50, LEAKY),                    # L = 2: generic path, no hidden layer
     ([784, 1200, 10], 24, RELU),               # one wide hidden layer (19 column groups backward)
     ([40, 24, 1100], 6, LEAKY),                # more than 1024 outputs: the output kernel's three-pass form
+    ([1100, 1100, 10], 20, TANH),              # more than 1024 gradient tiles of 32x32: the 64x64 one-launch gradient kernel
 ])
 def test_more_shapes_take_every_path(gnn, oracle_mod, dims, B, inner):
     rng = np.random.default_rng(13)
