@@ -177,7 +177,11 @@ int pick_tile(int M, int N) {
 
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
-    switch (pick_tile(p.M, p.N)) {
+    const int tile = pick_tile(p.M, p.N);
+    // A square grid of 256..511 tiles is ONE 4-wave workgroup per CU: nothing covers its barriers and LDS
+    // latencies.  Halving the tile along n puts two workgroups on every CU (config 4: 458 -> 447 us).
+    if (tile == 64 && (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64) < 512) { launch_gemm_t<64, 32, A_KC, B_KC, EPI>(h, cls, p); return; }
+    switch (tile) {
     case 128: launch_gemm_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;
     case 64: launch_gemm_t<64, 64, A_KC, B_KC, EPI>(h, cls, p); break;
     default: launch_gemm_t<32, 32, A_KC, B_KC, EPI>(h, cls, p); break;
