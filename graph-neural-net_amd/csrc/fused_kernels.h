@@ -424,4 +424,148 @@ __global__ __launch_bounds__(512) void grad_update64_kernel(GradParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// tail_kernel: for nets with at most 16 outputs (padded width 16) the LAST layer, the output rule and the
+// first backward product in one launch, per block of 16 batch rows:
+//   z = A_{L-2} . W_{L-2}           K split over the 8 waves in 16-wide chunks (as fwd_first_kernel)
+//   p = softmax(z), delta_{L-1} = p - y, loss, `>=` argmax          (SCE:357-376, 249-251, 213-217; MT:166-168)
+//   delta_{L-2} = (delta_{L-1} . W_{L-2}^T) * f'(a_{L-2})           (SCE:272-278; only when layer L-2 is hidden)
+// Off the row-block path these were three launches of ~4 us each around a few KB of data.
+// ------------------------------------------------------------------------------------------
+struct TailParams {
+    const float *A; int lda;      // activations of layer L-2 [rows][lda] (the inputs when L = 2)
+    const float *W;               // W_{L-2} [K][16]
+    const float *Y; int ldy;      // expected rows (may be null)
+    float *prob; float *delta_out; // [rows][16], may be null
+    float *loss; int32_t *label;  // [rows], may be null
+    float *delta_prev; int ldp;   // delta_{L-2} [rows][ldp], null = not wanted (forward only, or L = 2)
+    int K;                        // padded width of layer L-2
+    int k_true;                   // its logical width
+    int B, n_true;                // live rows, logical outputs
+    int act;                      // inner activation (for f')
+};
+
+__global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
+    constexpr int NW = 8, MAXC = 8, RLD = 20;
+    __shared__ __attribute__((aligned(16))) float red[NW * 16 * RLD];
+    __shared__ __attribute__((aligned(16))) float dl[16 * RLD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int k16 = p.K / 16;
+    const int c_begin = (int)((long)wave * k16 / NW), c_end = (int)((long)(wave + 1) * k16 / NW);
+    const float *arow = p.A + (size_t)(m0 + fr) * p.lda + 4 * fq;
+    const float *wcol = p.W + (size_t)(4 * fq) * 16 + fr;
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int cb = c_begin; cb < c_end; cb += MAXC) {
+        float4 a[MAXC];
+        float b[MAXC][4];
+#pragma unroll
+        for (int i = 0; i < MAXC; i++) {
+            const int c = cb + i;
+            if (c < c_end) {
+                a[i] = *reinterpret_cast<const float4 *>(arow + c * 16);
+                const float *w = wcol + (size_t)(c * 16) * 16;
+                b[i][0] = w[0]; b[i][1] = w[16]; b[i][2] = w[32]; b[i][3] = w[48];
+            } else {
+                a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                b[i][0] = b[i][1] = b[i][2] = b[i][3] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXC; i++) {
+            f32x4 &acc = (i & 1) ? acc1 : acc0;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i][3], acc, 0, 0, 0);
+        }
+    }
+    const f32x4 acc = acc0 + acc1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[(wave * 16 + fq * 4 + r) * RLD + fr] = acc[r];
+    __syncthreads();
+
+    // ---- output rule: thread (m = t/4, q = t%4) holds logits 4q..4q+3 of row m; a row is one quad of lanes ----
+    if (t < 64) {
+        const int m = t >> 2, q = t & 3;
+        const int row = m0 + m;
+        const bool live_row = row < p.B;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NW; w++) z += *reinterpret_cast<const f32x4 *>(&red[(w * 16 + m) * RLD + q * 4]);
+        float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.Y && live_row) yv = *reinterpret_cast<const float4 *>(p.Y + (size_t)row * p.ldy + q * 4);
+        const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+        // `>=` scan in ascending index (MT:166-168): ties -> highest index; NaN anywhere -> label 0 (see output_layer_kernel)
+        float mx = -__builtin_inff();
+        int best = -1;
+        bool has_nan = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int c = 4 * q + j;
+            if (c < p.n_true) {
+                has_nan |= (z[j] != z[j]);
+                if (z[j] >= mx) { mx = z[j]; best = c; }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o <= 2; o <<= 1) {
+            const float ov = __shfl_xor(mx, o);
+            const int ob = __shfl_xor(best, o);
+            if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
+            has_nan |= (__shfl_xor((int)has_nan, o) != 0);
+        }
+        float e[4], s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            e[j] = (4 * q + j < p.n_true) ? __expf(z[j] - mx) : 0.f;
+            s += e[j];
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float inv = 1.f / s, lse = mx + __logf(s);
+        float l = 0.f;
+        f32x4 pr, dd;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool live = live_row && 4 * q + j < p.n_true;
+            pr[j] = live ? e[j] * inv : 0.f;
+            const float y1 = live ? yy[j] : 0.f;
+            dd[j] = live ? pr[j] - y1 : 0.f;                     // SCE:250
+            if (live && y1 != 0.f) l += y1 * (lse - z[j]);       // -y ln p, SCE:216
+        }
+        l += __shfl_xor(l, 1);
+        l += __shfl_xor(l, 2);
+        if (p.prob) *reinterpret_cast<f32x4 *>(p.prob + (size_t)row * 16 + q * 4) = pr;
+        if (p.delta_out) *reinterpret_cast<f32x4 *>(p.delta_out + (size_t)row * 16 + q * 4) = dd;
+        *reinterpret_cast<f32x4 *>(&dl[m * RLD + q * 4]) = dd;
+        if (has_nan) best = 0;
+        if (q == 0) {
+            if (p.loss) p.loss[row] = live_row ? l : 0.f;
+            if (p.label) p.label[row] = live_row ? best : -1;
+        }
+    }
+    if (!p.delta_prev) return;
+    __syncthreads();
+
+    // ---- delta_{L-2}[16 x K]: one 16-column tile per wave at a time; k = 4*fq + i for the i-th MFMA on both operands ----
+    const f32x4 da = *reinterpret_cast<const f32x4 *>(&dl[fr * RLD + 4 * fq]); // delta_{L-1}[m = fr][4fq..4fq+3]
+    for (int nt = wave; nt < k16; nt += NW) {
+        const int n = nt * 16 + fr;
+        const f32x4 wb = *reinterpret_cast<const f32x4 *>(p.W + (size_t)n * 16 + 4 * fq); // W[n][4fq..4fq+3]
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; i++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(da[i], wb[i], c, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = m0 + fq * 4 + r;
+            const bool live = row < p.B && n < p.k_true;
+            const float a = p.A[(size_t)row * p.lda + n];
+            p.delta_prev[(size_t)row * p.ldp + n] = live ? c[r] * act_prime_from_a(p.act, a) : 0.f;
+        }
+    }
+}
+
 } // namespace gnn

@@ -192,10 +192,10 @@ constexpr int FIRST_NW = 8;  // waves per fwd_first_kernel workgroup (K split in
 
 // ---- forward (SCE:164-198): a0 = f(x) rows, B live rows ------------------------------------
 // leaves act[1..L-2], logits; the output kernel is launched by the caller via run_output.
-void forward(gnn_mlp *h, const float *a0, int B, int first_l = 1) {
+void forward(gnn_mlp *h, const float *a0, int B, int first_l = 1, bool stop_before_last = false) {
     const int B_pad = pad_up(B);
     const float *in = (first_l == 1) ? a0 : h->act[first_l - 1];
-    for (int l = first_l; l < h->L; l++) {
+    for (int l = first_l; l < h->L - (stop_before_last ? 1 : 0); l++) {
         GemmParams p{};
         p.A = in; p.lda = h->ld[l - 1];
         p.B = h->W + h->w_off[l - 1]; p.ldb = h->ld[l];
@@ -245,10 +245,10 @@ void run_output(gnn_mlp *h, const float *y, int B, bool want_prob, bool want_del
 // fused_update: G_l is consumed by the SGD epilogue and never written (single GPU);
 // otherwise G_l goes to the flat gradient buffer for the caller's all-reduce.
 void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_over_b, float momentum,
-              bool data_only = false) {
+              bool data_only = false, bool have_last_delta = false) {
     const int B_pad = pad_up(B);
     for (int l = h->L - 2; l >= 0; l--) {
-        if (l >= 1) { // delta_l = (delta_{l+1} . W_l^T) * f'(z_l)   -- before W_l is touched
+        if (l >= 1 && !(have_last_delta && l == h->L - 2)) { // delta_l = (delta_{l+1} . W_l^T) * f'(z_l)   -- before W_l is touched
             GemmParams p{};
             p.A = h->delta[l + 1]; p.lda = h->ld[l + 1];
             p.B = h->W + h->w_off[l]; p.ldb = h->ld[l + 1];
@@ -540,16 +540,41 @@ HybridChoice hybrid_choice(const gnn_mlp *h, int B) {
     return c;
 }
 
+// Nets with at most 16 outputs, off the row-block path: last layer + output rule (+ delta_{L-2}) in one launch
+bool use_tail(const gnn_mlp *h) {
+    const char *env = getenv("GNN_MLP_TAIL"); // tests: "0" = the three-launch form
+    const bool off = env && !strcmp(env, "0");
+    return !off && h->dtype == GNN_DTYPE_F32 && h->out_kind == GNN_OUT_SOFTMAX_CE && h->ld[h->L - 1] == 16;
+}
+void launch_tail(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob, bool want_loss, bool want_label) {
+    const int Lm = h->L - 1;
+    TailParams t{};
+    t.A = (Lm == 1) ? a0 : h->act[Lm - 1]; t.lda = h->ld[Lm - 1];
+    t.W = h->W + h->w_off[Lm - 1];
+    t.Y = y; t.ldy = h->ld[Lm];
+    t.prob = want_prob ? h->prob : nullptr;
+    t.delta_out = backward ? h->delta[Lm] : nullptr;
+    t.loss = want_loss ? h->lossv : nullptr;
+    t.label = want_label ? h->labels : nullptr;
+    t.delta_prev = (backward && Lm >= 2) ? h->delta[Lm - 1] : nullptr; t.ldp = h->ld[Lm - 1];
+    t.K = h->ld[Lm - 1]; t.k_true = h->dims[Lm - 1];
+    t.B = B; t.n_true = h->dims[Lm];
+    t.act = h->inner_act;
+    launch_timed(h, -1, tail_kernel, dim3(pad_up(B) / 16), dim3(512), 0, t);
+}
+
 // the three shapes every entry point is made of
 void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_prob, bool want_loss, bool want_label) {
     if (h->mid4) { fused_forward(h, a0, y, B, false, want_prob, want_loss, want_label); return; }
+    const bool tail = use_tail(h);
     if (h->mid_generic && hybrid_choice(h, B).first) {
         launch_fwd_first(h, a0, B);
-        forward(h, a0, B, 2);
+        forward(h, a0, B, 2, tail);
     } else {
-        forward(h, a0, B);
+        forward(h, a0, B, 1, tail);
     }
-    run_output(h, y, B, want_prob, false, want_loss, want_label);
+    if (tail) launch_tail(h, a0, y, B, false, want_prob, want_loss, want_label);
+    else run_output(h, y, B, want_prob, false, want_loss, want_label);
 }
 void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum) {
     if (h->mid4) {
@@ -558,18 +583,20 @@ void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_
         return;
     }
     const HybridChoice c = h->mid_generic ? hybrid_choice(h, B) : HybridChoice{false, false};
+    const bool tail = use_tail(h);
     if (c.first) {
         launch_fwd_first(h, a0, B);
-        forward(h, a0, B, 2);
+        forward(h, a0, B, 2, tail);
     } else {
-        forward(h, a0, B);
+        forward(h, a0, B, 1, tail);
     }
-    run_output(h, y, B, false, true, false, false);
+    if (tail) launch_tail(h, a0, y, B, true, false, false, false);
+    else run_output(h, y, B, false, true, false, false);
     if (c.grad) {
-        backward(h, a0, B, false, 0.f, 0.f, true); // delta_1..delta_{L-2} only
+        backward(h, a0, B, false, 0.f, 0.f, true, tail); // delta_1..delta_{L-2} only (delta_{L-2} came from the tail kernel)
         fused_gradient(h, a0, B, fused_update, step_over_b, momentum);
     } else {
-        backward(h, a0, B, fused_update, step_over_b, momentum);
+        backward(h, a0, B, fused_update, step_over_b, momentum, false, tail);
     }
 }
 

@@ -405,6 +405,40 @@ def test_hybrid_choices_agree_with_oracle(gnn, oracle_mod, monkeypatch, mask):
     assert np.abs(net.get_momentum() - ref.get_momentum()).max() <= 3 * W_ATOL
 
 
+@pytest.mark.parametrize("tail", ["0", None])
+@pytest.mark.parametrize("dims,B", [([200, 512, 272, 10], 27), ([300, 10], 50), ([90, 600, 300, 16], 33)])
+def test_tail_kernel_and_three_launch_form_agree_with_oracle(gnn, oracle_mod, monkeypatch, tail, dims, B):
+    """Off the row-block path, nets with <= 16 outputs run last layer + softmax/loss/argmax + the first
+    backward product as ONE kernel (tail_kernel); GNN_MLP_TAIL=0 keeps the three launches.  Both against
+    the oracle: probabilities, loss, labels, gradients, steps."""
+    if tail is None: monkeypatch.delenv("GNN_MLP_TAIL", raising=False)
+    else: monkeypatch.setenv("GNN_MLP_TAIL", tail)
+    X, Y = make_batch(dims, B, seed=91, sparse=True)
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    ref = oracle_mod.OracleNet(dims)
+    ref.set_alloc_per_sample(0)
+    w = net.get_weights() * 0.3
+    net.set_weights(w); ref.set_weights(w)
+    pr = ref.propagate(X)
+    assert np.abs(net.propagate(X) - pr).max() <= P_ATOL
+    lr = ref.calculate_loss(X, Y)
+    assert np.abs(net.calculateLoss(X, Y) - lr).max() <= 2e-4 * np.abs(lr).max() + 2e-4
+    z = np.sort(pr, axis=1)
+    sure = (z[:, -1] - z[:, -2]) > 1e-6
+    assert np.array_equal(net.argmax(X)[sure], ref.argmax(X)[sure])
+    g = net.calculateWeightGradient(X, Y)
+    gr = sum(ref.calculate_weight_gradient(X[b], Y[b]) for b in range(B))
+    off = 0
+    for l in range(len(dims) - 1):
+        n = dims[l] * dims[l + 1]
+        grl = gr[off:off + n].reshape(dims[l], dims[l + 1]); off += n
+        assert np.abs(g[l] - grl).max() <= 3e-5 * np.abs(grl).max() + 1e-9, "layer %d" % l
+    for s in range(3):
+        net.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+        ref.gradient_step(X, Y, 0.0125, 0.9)
+    assert np.abs(net.get_weights() - ref.get_weights()).max() <= 3 * W_ATOL
+
+
 def test_train_range_graph_replay_equals_stepwise(gnn, monkeypatch):
     """With GNN_MLP_GRAPH=1 gnn_mlp_train_range replays a captured hipGraph of one pass when the
     request covers whole passes: same kernels, same order -> bitwise equal to step-by-step calls;
