@@ -220,22 +220,20 @@ __global__ __launch_bounds__(NTHR) void grad_update_kernel(GradParams p) {
     const size_t e_off = (size_t)(m0 + er) * L.ldd + n0 + eq * 4;
     GNN_STAMP_AT(p.stamps, 0);
     GNN_STAMP_REAL(p.stamps, 4);
-    // W / V rows first: their latency hides under the GEMM
     float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f), v_old = w_old;
-    if (FUSED && e_ok) {
-        w_old = *reinterpret_cast<const float4 *>(L.W + e_off);
-        v_old = *reinterpret_cast<const float4 *>(L.V + e_off);
-    }
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < p.K; k0 += KC) {
         const int kc = (p.K - k0 < KC) ? p.K - k0 : KC;
         if (k0) __syncthreads();
-        // 32 floats (8 float4) per row per operand; thread -> (row = idx / 8, q = idx % 8)
+        // 32 floats (8 float4) per row per operand; thread -> (row = idx / 8, q = idx % 8).  The operand
+        // panels are on the critical path and are requested FIRST; the W / V rows of the update are needed
+        // only after the GEMM and queue behind them (their latency hides under the MFMAs)
+        float4 va[KC * 8 / NTHR], vd[KC * 8 / NTHR];
 #pragma unroll
         for (int i = 0; i < KC * 8 / NTHR; i++) {
             const int idx = t + i * NTHR, k = idx >> 3, q = idx & 7;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vd = va;
+            va[i] = make_float4(0.f, 0.f, 0.f, 0.f); vd[i] = va[i];
             if (k < kc) {
                 size_t a_row = (size_t)(k0 + k);
                 bool a_live = true;
@@ -243,11 +241,19 @@ __global__ __launch_bounds__(NTHR) void grad_update_kernel(GradParams p) {
                     a_live = k0 + k < p.k_true;
                     a_row = a_live ? (size_t)p.row_idx[k0 + k] : 0;
                 }
-                if (a_live && m0 + q * 4 < L.M) va = *reinterpret_cast<const float4 *>(L.A + a_row * L.lda + m0 + q * 4);
-                if (n0 + q * 4 < L.N) vd = *reinterpret_cast<const float4 *>(L.D + (size_t)(k0 + k) * L.ldd + n0 + q * 4);
+                if (a_live && m0 + q * 4 < L.M) va[i] = *reinterpret_cast<const float4 *>(L.A + a_row * L.lda + m0 + q * 4);
+                if (n0 + q * 4 < L.N) vd[i] = *reinterpret_cast<const float4 *>(L.D + (size_t)(k0 + k) * L.ldd + n0 + q * 4);
             }
-            *reinterpret_cast<float4 *>(&As[k * LDS_LD + q * 4]) = va;
-            *reinterpret_cast<float4 *>(&Ds[k * LDS_LD + q * 4]) = vd;
+        }
+        if (FUSED && e_ok && k0 == 0) {
+            w_old = *reinterpret_cast<const float4 *>(L.W + e_off);
+            v_old = *reinterpret_cast<const float4 *>(L.V + e_off);
+        }
+#pragma unroll
+        for (int i = 0; i < KC * 8 / NTHR; i++) {
+            const int idx = t + i * NTHR, k = idx >> 3, q = idx & 7;
+            *reinterpret_cast<float4 *>(&As[k * LDS_LD + q * 4]) = va[i];
+            *reinterpret_cast<float4 *>(&Ds[k * LDS_LD + q * 4]) = vd[i];
         }
         __syncthreads();
         GNN_STAMP_AT(p.stamps, 1);
