@@ -154,6 +154,13 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_f<DPP_MIRROR>(v);
     return v;
 }
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+    return v;
+}
 // (value, index) argmax over the row of 16: larger value wins, ties -> higher index (MT:166-168)
 __device__ __forceinline__ void row16_argmax(float &v, int &ix) {
 #define GNN_ARGMAX_STEP(CTRL)                                          \
@@ -394,7 +401,44 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     GNN_STAMP4(2);
 
     // ---- output layer: wave 0, one DPP row of 16 lanes per batch row ----
-    if (wave == 0) {
+    if (wave == 0 && OUTK == 0 && m.ld[Lm] == 16) {
+        // at most 16 classes: ONE logit per lane, kept in registers -- the general form below walks the
+        // row three times through LDS and always reduces loss, label and NaN flag; this wave works alone
+        // while the other fifteen wait, so its dependent chain is kernel time (1 900 -> ~700 cycles)
+        const int nt = m.d[Lm];
+        const int mr = lane >> 4, c0 = lane & 15;
+        const int row = row0 + mr;
+        const bool valid = c0 < nt, live = row < p.B && valid;
+        float zv = 0.f;
+        {
+            const int KS = m.ks_fwd[Lm]; // (kr <= 16: one column group of 64)
+            if (c0 < m.kr[Lm])
+                for (int ks = 0; ks < KS; ks++) zv += smem[m.off_scratch + (ks * 4 + mr) * 64 + c0];
+        }
+        float mx = valid ? zv : -__builtin_inff();
+        int best = valid ? c0 : -1;
+        if (p.label) { // MT:166-168 incl. the NaN rule (see output_layer_kernel)
+            const float nan_flag = (valid && zv != zv) ? 1.f : 0.f;
+            row16_argmax(mx, best);
+            if (row16_sum(nan_flag) > 0.f) best = 0;
+        } else {
+            mx = row16_max(mx);
+        }
+        const float e = valid ? __expf(zv - mx) : 0.f;
+        const float s = row16_sum(e);
+        const float pr = live ? e * (1.f / s) : 0.f;
+        const float yy = (live && p.Y) ? smem[m.off_y + mr * 16 + c0] : 0.f;
+        const float dd = live ? pr - yy : 0.f;                       // SCE:250
+        if (p.prob) p.prob[(size_t)row * 16 + c0] = pr;
+        smem[m.off_dl[Lm] + mr * (16 + 4) + c0] = dd;
+        if (BACKWARD) p.delta[Lm][(size_t)row * 16 + c0] = dd;
+        if (p.loss) {
+            const float lse = mx + __logf(s);
+            const float lsum = row16_sum((live && yy != 0.f) ? yy * (lse - zv) : 0.f); // -y ln p, SCE:216
+            if (c0 == 0) p.loss[row] = row < p.B ? lsum : 0.f;
+        }
+        if (p.label && c0 == 0) p.label[row] = row < p.B ? best : -1;
+    } else if (wave == 0) {
         const int N = m.ld[Lm], nt = m.d[Lm];
         const int mr = lane >> 4, c0 = lane & 15;
         const int row = row0 + mr;
