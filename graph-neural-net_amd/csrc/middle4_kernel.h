@@ -368,9 +368,15 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     constexpr bool IS_STATIC = NSLOT > 0;
 
     // ---- forward: layers 2 .. L-1 (SCE:172-194) ----
+    // Row tail: with at most 16 classes and a last hidden layer of at most 128 neurons, ONE wave per batch
+    // row does the last layer, the output rule and delta_{L-2} on its own (vector FMAs, the wave's own LDS
+    // traffic, no workgroup barrier in between): as three barrier-separated phases these took 3 400 cycles
+    // in which one to six waves worked and the rest were parked (SQ_WAIT_ANY was 61 % of the wave cycles).
+    const bool rowtail = OUTK == 0 && Lm >= 2 && m.ld[Lm] == 16 && m.kr[Lm - 1] <= 128;
 #pragma unroll
     for (int l = 2; l < MAX_LAYERS; l++) {
         if (l > Lm) break;
+        if (rowtail && l == Lm) break;
         const int N = m.ld[l], G = (m.kr[l] + 63) / 64, gw = G * 64, KS = m.ks_fwd[l], k4n = m.kr[l - 1] / 4;
         if (wave < G * KS) {
             const int g = wave % G, ks = wave / G;
@@ -401,7 +407,86 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     GNN_STAMP4(2);
 
     // ---- output layer: wave 0, one DPP row of 16 lanes per batch row ----
-    if (wave == 0 && OUTK == 0 && m.ld[Lm] == 16) {
+    if (rowtail) {
+        if (wave < 4) {
+            const int r = wave, row = row0 + r;
+            const int K = m.kr[Lm - 1], nt = m.d[Lm], lwl = m.lw[Lm - 1], ldp = m.ld[Lm - 1];
+            const float *a = smem + m.off_act[Lm - 1] + r * (ldp + 4);
+            const float *Wl = smem + m.off_w[Lm - 1];
+            const int ks = lane >> 4, c = lane & 15;
+            // logits: lane (ks, c) sums k = ks, ks+4, .. of column c; the four partial sums meet by lane exchange
+            float zv = 0.f;
+            if (c < m.kr[Lm]) {
+                constexpr int UK = 8; // reads of 8 steps in flight before their FMAs: a lone wave hides no LDS latency
+                int k = ks;
+                for (; k + 4 * (UK - 1) < K; k += 4 * UK) {
+                    float av[UK], wv[UK];
+#pragma unroll
+                    for (int u = 0; u < UK; u++) { av[u] = a[k + 4 * u]; wv[u] = Wl[(k + 4 * u) * lwl + c]; }
+#pragma unroll
+                    for (int u = 0; u < UK; u++) zv = __builtin_fmaf(av[u], wv[u], zv);
+                }
+                for (; k < K; k += 4) zv = __builtin_fmaf(a[k], Wl[k * lwl + c], zv);
+            }
+            zv += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __builtin_bit_cast(int, zv)));
+            zv += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, zv)));
+            // output rule on the DPP row of 16 (all four rows of the wave hold the same 16 logits)
+            const bool valid = c < nt, live = row < p.B && valid;
+            float mx = valid ? zv : -__builtin_inff();
+            int best = valid ? c : -1;
+            if (p.label) { // MT:166-168 incl. the NaN rule (see output_layer_kernel)
+                const float nan_flag = (valid && zv != zv) ? 1.f : 0.f;
+                row16_argmax(mx, best);
+                if (row16_sum(nan_flag) > 0.f) best = 0;
+            } else {
+                mx = row16_max(mx);
+            }
+            const float e = valid ? __expf(zv - mx) : 0.f;
+            const float s = row16_sum(e);
+            const float pr = live ? e * (1.f / s) : 0.f;
+            const float yy = (live && p.Y) ? smem[m.off_y + r * 16 + c] : 0.f;
+            const float dd = live ? pr - yy : 0.f;                   // SCE:250
+            float *dlast = smem + m.off_dl[Lm] + r * (16 + 4);
+            if (ks == 0) {
+                if (p.prob) p.prob[(size_t)row * 16 + c] = pr;
+                dlast[c] = dd;
+                if (BACKWARD) p.delta[Lm][(size_t)row * 16 + c] = dd;
+            }
+            if (p.loss) {
+                const float lse = mx + __logf(s);
+                const float lsum = row16_sum((live && yy != 0.f) ? yy * (lse - zv) : 0.f); // -y ln p, SCE:216
+                if (lane == 0) p.loss[row] = row < p.B ? lsum : 0.f;
+            }
+            if (p.label && lane == 0) p.label[row] = row < p.B ? best : -1;
+            if (BACKWARD) {
+                // delta_{L-2}[n] = (sum_c delta_{L-1}[c] W[n][c]) f'(a[n]): lane n and n + 64; the wave reads back
+                // its own 16 deltas (LDS keeps a wave's accesses in order); only the copied columns of W are used
+                f32x4 d4[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) d4[q] = *reinterpret_cast<const f32x4 *>(dlast + 4 * q);
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int n = lane + 64 * half;
+                    if (n < ldp) {
+                        float acc = 0.f;
+                        if (n < K) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                if (4 * q < m.kr[Lm]) {
+                                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(Wl + n * lwl + 4 * q);
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) acc = __builtin_fmaf(d4[q][j], w4[j], acc);
+                                }
+                            }
+                        }
+                        const float v = (row < p.B && n < m.d[Lm - 1]) ? acc * act_prime_from_a(ACT, a[n]) : 0.f;
+                        if (Lm - 1 > 1) smem[m.off_dl[Lm - 1] + r * (ldp + 4) + n] = v;
+                        p.delta[Lm - 1][(size_t)row * ldp + n] = v;
+                    }
+                }
+            }
+        }
+    } else if (wave == 0 && OUTK == 0 && m.ld[Lm] == 16) {
         // at most 16 classes: ONE logit per lane, kept in registers -- the general form below walks the
         // row three times through LDS and always reduces loss, label and NaN flag; this wave works alone
         // while the other fifteen wait, so its dependent chain is kernel time (1 900 -> ~700 cycles)
@@ -512,6 +597,7 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     for (int li = 0; li < MAX_LAYERS; li++) {
         const int l = Lm - 1 - li;
         if (l < 1) break;
+        if (rowtail && l == Lm - 1) continue; // done by the row tail
         const int N = m.ld[l], NR = m.kr[l], G = (NR + 63) / 64, gw = G * 64, KS = m.ks_bwd[l];
         const int k4n = m.kr[l + 1] / 4;
         if (wave < G * KS) {
