@@ -372,7 +372,7 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     // row does the last layer, the output rule and delta_{L-2} on its own (vector FMAs, the wave's own LDS
     // traffic, no workgroup barrier in between): as three barrier-separated phases these took 3 400 cycles
     // in which one to six waves worked and the rest were parked (SQ_WAIT_ANY was 61 % of the wave cycles).
-    const bool rowtail = OUTK == 0 && Lm >= 2 && m.ld[Lm] == 16 && m.kr[Lm - 1] <= 128;
+    const bool rowtail = Lm >= 2 && m.ld[Lm] == 16 && m.kr[Lm - 1] <= 128;
 #pragma unroll
     for (int l = 2; l < MAX_LAYERS; l++) {
         if (l > Lm) break;
@@ -432,29 +432,48 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
             zv += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, zv)));
             // output rule on the DPP row of 16 (all four rows of the wave hold the same 16 logits)
             const bool valid = c < nt, live = row < p.B && valid;
-            float mx = valid ? zv : -__builtin_inff();
-            int best = valid ? c : -1;
-            if (p.label) { // MT:166-168 incl. the NaN rule (see output_layer_kernel)
-                const float nan_flag = (valid && zv != zv) ? 1.f : 0.f;
-                row16_argmax(mx, best);
-                if (row16_sum(nan_flag) > 0.f) best = 0;
-            } else {
-                mx = row16_max(mx);
-            }
-            const float e = valid ? __expf(zv - mx) : 0.f;
-            const float s = row16_sum(e);
-            const float pr = live ? e * (1.f / s) : 0.f;
             const float yy = (live && p.Y) ? smem[m.off_y + r * 16 + c] : 0.f;
-            const float dd = live ? pr - yy : 0.f;                   // SCE:250
+            float out, dd, lterm, mx;   // reported output, delta, this lane's loss term, argmax key
+            int best = valid ? c : -1;
+            float nan_flag = 0.f;
+            float lse = 0.f;
+            if (OUTK == 0) {
+                mx = valid ? zv : -__builtin_inff();
+                if (p.label) { // MT:166-168 incl. the NaN rule (see output_layer_kernel): any NaN logit -> label 0
+                    nan_flag = (valid && zv != zv) ? 1.f : 0.f;
+                    row16_argmax(mx, best);
+                } else {
+                    mx = row16_max(mx);
+                }
+                const float e = valid ? __expf(zv - mx) : 0.f;
+                const float s = row16_sum(e);
+                out = live ? e * (1.f / s) : 0.f;
+                dd = live ? out - yy : 0.f;                          // SCE:250
+                if (p.loss) lse = mx + __logf(s);
+                lterm = (live && yy != 0.f) ? yy * (lse - zv) : 0.f; // -y ln p, SCE:216
+            } else {
+                const float av = act_fn(p.last_act, zv);             // GNN:215-218
+                const float df = av - yy;
+                out = live ? av : 0.f;
+                dd = live ? df * act_prime_from_a(p.last_act, av) : 0.f; // GNN:267-271
+                lterm = live ? 0.5f * df * df : 0.f;
+                const bool in_scan = live && av == av;               // `x >= NaN` and `NaN >= x` are false: a NaN is never selected
+                mx = in_scan ? av : -__builtin_inff();
+                if (!in_scan) best = -1;
+                if (p.label) { // element-wise output: only a NaN at index 0 is sticky (MT:166-168)
+                    nan_flag = (live && c == 0 && av != av) ? 1.f : 0.f;
+                    row16_argmax(mx, best);
+                }
+            }
+            if (p.label && row16_sum(nan_flag) > 0.f) best = 0;
             float *dlast = smem + m.off_dl[Lm] + r * (16 + 4);
             if (ks == 0) {
-                if (p.prob) p.prob[(size_t)row * 16 + c] = pr;
+                if (p.prob) p.prob[(size_t)row * 16 + c] = out;
                 dlast[c] = dd;
                 if (BACKWARD) p.delta[Lm][(size_t)row * 16 + c] = dd;
             }
             if (p.loss) {
-                const float lse = mx + __logf(s);
-                const float lsum = row16_sum((live && yy != 0.f) ? yy * (lse - zv) : 0.f); // -y ln p, SCE:216
+                const float lsum = row16_sum(lterm);
                 if (lane == 0) p.loss[row] = row < p.B ? lsum : 0.f;
             }
             if (p.label && lane == 0) p.label[row] = row < p.B ? best : -1;

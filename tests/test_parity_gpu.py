@@ -475,6 +475,25 @@ def test_argmax_nan_rule(gnn, oracle_mod):
         assert np.array_equal(net.argmax(X), np.zeros(4, dtype=np.int32))
 
 
+@pytest.mark.parametrize("poison", ["last_column", "first_column"])
+def test_argmax_nan_rule_elementwise_output(gnn, oracle_mod, poison):
+    """GeneralNeuralNet outputs are element-wise, so one NaN weight poisons ONE output: at an index
+    > 0 it is never selected (`NaN >= x` is false), at index 0 it is sticky (MT:166-168)."""
+    for dims in ([30, 21, 18, 5], [64, 10]):
+        net = gnn.GeneralNeuralNet(dims, inner_act=SIGMOID, last_act=IDENT, max_batch=6)
+        ref = oracle_mod.OracleNet(dims, out_kind=oracle_mod.OUT_ACT_LOSS, inner_act=SIGMOID, last_act=IDENT)
+        w = net.get_weights()
+        w[-1 if poison == "last_column" else -dims[-1]] = np.nan   # last row of the last layer, last / first output
+        net.set_weights(w); ref.set_weights(w)
+        X = np.random.default_rng(3).random((6, dims[0])) + 0.1
+        want = ref.argmax(X)
+        if poison == "first_column":
+            assert np.all(want == 0)
+        else:
+            assert np.all(want != dims[-1] - 1)
+        assert np.array_equal(net.argmax(X), want)
+
+
 def test_runtime_specialisation_is_bitwise_identical(gnn):
     """gnn_mlp_specialize (hiprtc instantiation of the fused path's kernel template for this
     net's layer sizes) changes speed only: same arithmetic, same order, bitwise equal results."""
