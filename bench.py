@@ -1,21 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- training samples/sec of the MLP mini-batch SGD path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
 A "step" is one gradientStep (SCE:297-346: forward + backward + [all-reduce] + momentum update)
 on one batch of synthetic 784-dim inputs already resident in HBM.  The workload at every N is
 BASELINE.json configs[1] per GPU: 784-300-100-10, fp32, batch 128 per GPU (weak scaling: the
 global batch is 128*N, sharded by rows, ONE all-reduce(SUM) of the flat weight gradient per step
-over RCCL, identical update on every rank).  Rank 0 prints ONE JSON line.
+over RCCL, identical update on every rank).  `--dtype bf16` runs configs[2]'s arithmetic (bf16
+GEMM operands, f32 accumulate and masters) on the same shape; the headline stays f32.
+Rank 0 prints ONE JSON line.
+
+N > 1 is one process per GPU.  Either the caller starts the ranks (torch.distributed.run: RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or -- when `--gpus N` arrives with no
+WORLD_SIZE, which is how the driver calls it -- this file starts them itself: the launcher below
+imports neither torch nor the HIP library, spawns N fresh children of this script, relays rank 0's
+line and returns the worst exit code.
+
+Graph or eager (data-parallel path) is decided BEFORE anything runs: `--dp-mode graph` captures
+one pass over the resident batches -- kernels and the RCCL all-reduce -- into one HIP graph.  If
+that capture does not produce a graph, the stream it ran on is left invalidated and the process
+must not issue further GPU work (round 1: later HIP calls crashed): every rank exits with
+EXIT_CAPTURE_FAILED at once and the eager run happens in FRESH processes (the launcher starts a
+new group; a rank started by torch.distributed.run starts its own fresh child).
 """
 import argparse
+import datetime
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -23,18 +39,141 @@ if ROOT not in sys.path:
 
 DIMS = [784, 300, 100, 10]
 BATCH = 128
-STEP, MOMENTUM = 0.0125, 0.9  # MT:227-229
+N_BATCHES = 64                 # synthetic batches resident in HBM per rank
+STEP, MOMENTUM = 0.0125, 0.9   # MT:227-229
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF figure is 2:1 sparse)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+EXIT_CAPTURE_FAILED = 75       # a rank's stream capture did not produce a graph: rerun eager in fresh processes
+PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="GEMM operand type (f32 = BASELINE configs[1], the headline; bf16 = configs[2]'s arithmetic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-mode", choices=["auto", "graph", "eager"], default="auto",
+                    help="data-parallel path: hipGraph replay of the resident batches, or eager steps; "
+                         "auto = graph with the nccl (RCCL) backend, eager otherwise")
+    ap.add_argument("--no-graph", action="store_true", help="same as --dp-mode eager")
+    ap.add_argument("--dp-path", action="store_true",
+                    help="run the data-parallel code path (compute -> all_reduce -> update) even at N=1")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control flow on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--inject-capture-failure", action="store_true",
+                    help="test hook: a non-capturable call inside the capture, so that the capture really fails")
+    args = ap.parse_args(argv)
+    if args.no_graph:
+        args.dp_mode = "eager"
+    return args
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher: no torch, no HIP -- only child processes
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def child_argv(argv, dp_mode):
+    """The caller's flags with the graph/eager decision made explicit."""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a == "--dp-mode":
+            skip = True
+            continue
+        if a.startswith("--dp-mode=") or a == "--no-graph" or a == "--inject-capture-failure":
+            continue
+        out.append(a)
+    return out + ["--dp-mode", dp_mode]
+
+
+def run_group(argv, world, dp_mode, inject):
+    """Starts `world` fresh ranks of this script; returns (worst exit code, rank 0's stdout)."""
+    port = free_port()
+    cmd = [sys.executable, os.path.abspath(__file__)] + child_argv(argv, dp_mode)
+    if inject:
+        cmd.append("--inject-capture-failure")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GNN_BENCH_LAUNCHER="1")
+        procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=(r == 0)))
+    # rank 0's stdout is one short line: reading it at the end cannot fill the pipe
+    deadline_after_failure = None
+    ended_here = set()
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            # a rank died: its peers would wait in a collective for ever; give them a moment, then end them
+            if deadline_after_failure is None:
+                deadline_after_failure = time.time() + 20.0
+            elif time.time() > deadline_after_failure:
+                for i, p in enumerate(procs):
+                    if p.poll() is None:
+                        p.kill()          # exact PIDs of the children started above
+                        ended_here.add(i)
+        time.sleep(0.05)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    codes = [p.returncode for p in procs]
+    if any(c == EXIT_CAPTURE_FAILED for c in codes):
+        return EXIT_CAPTURE_FAILED, out0
+    worst = 0
+    for i, c in enumerate(codes):   # the code of a rank that failed by itself, not of the peers ended above
+        if c != 0 and (i not in ended_here or worst == 0):
+            worst = c if c > 0 else 128 - c
+            if i not in ended_here:
+                break
+    return worst, out0
+
+
+def launch(args, argv):
+    modes = [args.dp_mode]
+    if args.dp_mode == "auto":
+        # (a gloo collective cannot be captured; the test hook asks for the failing attempt anyway)
+        modes = ["graph", "eager"] if args.backend == "nccl" or args.inject_capture_failure else ["eager"]
+    rc, out0 = 1, ""
+    for i, mode in enumerate(modes):
+        rc, out0 = run_group(argv, args.gpus, mode, args.inject_capture_failure and mode == "graph")
+        if rc == 0:
+            lines = [l for l in out0.splitlines() if l.strip()]
+            if len(lines) != 1:
+                print("bench.py launcher: rank 0 printed %d lines instead of one" % len(lines), file=sys.stderr)
+                return 1
+            print(lines[0], flush=True)
+            return 0
+        if rc != EXIT_CAPTURE_FAILED or i + 1 == len(modes):
+            break
+        print("bench.py launcher: hipGraph capture failed in the ranks; starting fresh ranks in eager mode", file=sys.stderr)
+    print("bench.py launcher: ranks failed (exit code %d)" % rc, file=sys.stderr)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------
 def pmc_traffic(kernel_substring):
-    """L2<->fabric bytes per launch of a kernel from the committed rocprofv3 PMC passes
-    (profiles/r01/pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this very command,
-    FETCH_SIZE doubled as the gfx950 guide prescribes).  bench.py cannot collect PMCs itself."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    """L2<->fabric bytes per launch of a kernel from the committed rocprofv3 PMC passes (separate
+    FETCH_SIZE / WRITE_SIZE runs of this very command, FETCH_SIZE doubled as the gfx950 guide
+    prescribes; tools/pmc_summary.py).  bench.py cannot collect PMCs itself: the figure is from the
+    file named in roofline.traffic_source, and null when the file has no kernel of that name."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             for name, d in json.load(f)["kernels"].items():
                 if kernel_substring in name:
                     return round(d["traffic_bytes_per_launch"])
@@ -45,6 +184,7 @@ def pmc_traffic(kernel_substring):
 
 def synthetic(n, seed):
     """X ~ U[0,1) 784-dim, uniform one-hot labels; generated here, never shipped."""
+    import numpy as np
     rng = np.random.default_rng(seed)
     X = rng.random((n, DIMS[0]))
     Y = np.eye(DIMS[-1])[rng.integers(0, DIMS[-1], n)]
@@ -71,19 +211,17 @@ def cpu_baseline(seconds=12.0):
                       "SCE:297-346; C restatement, not a JVM run)" % (steps, BATCH)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="data-parallel path: eager steps, no hipGraph replay")
-    ap.add_argument("--dp-path", action="store_true",
-                    help="run the data-parallel code path (compute -> all_reduce -> update) even at N=1")
-    ap.add_argument("--backend", default="nccl",
-                    help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control flow on a one-GPU box")
-    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    args = ap.parse_args()
+def fresh_eager_child(argv):
+    """A rank started by torch.distributed.run whose capture failed: the eager run goes to a fresh
+    child process (same rank, next rendezvous port); this process only waits and relays."""
+    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29511")) + 1), GNN_BENCH_LAUNCHER="1")
+    cmd = [sys.executable, os.path.abspath(__file__)] + child_argv(argv, "eager")
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
+    return p.returncode, p.stdout
+
+
+def worker(args, argv):
+    import numpy as np
 
     # stdout carries ONE JSON line: libraries that chat on fd 1 (RCCL prints a version banner there,
     # gloo its connection report) are routed to stderr until the line is printed
@@ -91,14 +229,14 @@ def main():
     stdout_fd = os.dup(1)
     os.dup2(2, 1)
 
+    def emit(text):
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        print(text, flush=True)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
 
     import torch
     import gnn_amd
@@ -109,6 +247,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    dp_mode = None
     if world > 1 or args.dp_path:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -119,11 +258,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        dp_mode = args.dp_mode
+        if dp_mode == "auto":
+            dp_mode = "graph" if args.backend == "nccl" else "eager"
 
     K, W = args.steps, args.warmup
-    n_batches = 64
-    X, Y = synthetic(BATCH * n_batches, 1000 + rank)  # each rank owns its row shard of the global batch
-    net = gnn_amd.SoftmaxCrossEntropyNeuralNet(DIMS, device=local_rank, max_batch=BATCH)
+    bf16 = args.dtype == "bf16"
+    X, Y = synthetic(BATCH * N_BATCHES, 1000 + rank)  # each rank owns its row shard of the global batch
+    net = gnn_amd.SoftmaxCrossEntropyNeuralNet(DIMS, device=local_rank, max_batch=BATCH,
+                                               dtype=gnn_amd.DTYPE_BF16 if bf16 else gnn_amd.DTYPE_F32)
     net.upload_dataset(X, Y)
 
     def barrier():
@@ -132,43 +275,65 @@ def main():
         net.synchronize()
         torch.cuda.synchronize()
 
+    graphed = None
     if dist is None:
-        def run(first_batch, n):
-            net.train_range((first_batch % n_batches) * BATCH, BATCH, n, STEP, MOMENTUM)
+        def run(first_batch, n, eager=False):
+            net.train_range((first_batch % N_BATCHES) * BATCH, BATCH, n, STEP, MOMENTUM)
     else:
-        # data parallel (graph-neural-net_amd/data_parallel.py): kernels on torch's current stream,
-        # gradient buffer owned by torch so that RCCL reduces it in place, one all-reduce per step
+        # data parallel (graph-neural-net_amd/data_parallel.py): kernels on a torch side stream that
+        # is also the collective's stream, gradient buffer owned by torch so that RCCL reduces it in
+        # place, one all-reduce per step
         from gnn_amd import data_parallel as dp
         side = torch.cuda.Stream()
         stepper = dp.DataParallelStep(dp.HipEngine(net, torch, stream=side), dist, always_reduce=args.dp_path)
-        graphed = None
-        if not args.no_graph and args.backend == "nccl":  # (a gloo collective cannot be captured)
-            try:  # one pass over the 64 resident batches as ONE graph launch
-                graphed = dp.GraphedSteps(stepper, torch, side, [b * BATCH for b in range(n_batches)],
-                                          BATCH, STEP, MOMENTUM)
-            except Exception as e:  # capture of the collective not available: eager steps
-                if rank == 0:
-                    print("graph capture failed (%s: %s); running eager" % (type(e).__name__, str(e).splitlines()[0]), file=sys.stderr)
-                graphed = None
-                side = torch.cuda.Stream()       # the stream of a failed capture may stay unusable
-                stepper.engine.rebind_stream(side)
+        if dp_mode == "graph":
+            # one pass over the resident batches as ONE graph launch.  The ranks agree on the outcome
+            # through a CPU-side store (no GPU call after a failed capture), then either all go on or
+            # all leave.
+            ok = True
+            try:
+                graphed = dp.GraphedSteps(stepper, torch, side, [b * BATCH for b in range(N_BATCHES)],
+                                          BATCH, STEP, MOMENTUM, inject_failure=args.inject_capture_failure)
+            except Exception as e:
+                ok = False
+                print("rank %d: hipGraph capture failed (%s: %s)" % (rank, type(e).__name__,
+                                                                     (str(e).splitlines() or [""])[0]), file=sys.stderr)
+            all_ok = ok
+            if world > 1:
+                store = dist.TCPStore("127.0.0.1", int(os.environ["MASTER_PORT"]) + 3, world, rank == 0,
+                                      timeout=datetime.timedelta(seconds=120))
+                store.set("cap%d" % rank, "1" if ok else "0")
+                all_ok = all(store.get("cap%d" % r) == b"1" for r in range(world))
+                store.set("seen%d" % rank, "1")
+                if rank == 0:   # the store's server stays up until every rank has read the verdict
+                    for r in range(world):
+                        store.get("seen%d" % r)
+            if not all_ok:
+                # No further GPU work in this process, and no teardown that could touch the
+                # invalidated stream or wait for peers: leave at once.
+                sys.stderr.flush()
+                if os.environ.get("GNN_BENCH_LAUNCHER") == "1":
+                    os._exit(EXIT_CAPTURE_FAILED)      # our launcher starts fresh ranks in eager mode
+                rc, out = fresh_eager_child(argv)      # started by torch.distributed.run: own fresh child
+                if rank == 0 and rc == 0:
+                    emit(out.strip())
+                os._exit(rc)
 
         def run(first_batch, n, eager=False):
             s = 0
-            with torch.cuda.stream(side):
-                while s < n:
-                    b = (first_batch + s) % n_batches
-                    if graphed is not None and not eager and b == 0 and n - s >= n_batches:
-                        graphed.replay()
-                        s += n_batches
-                    else:
-                        stepper.step(b * BATCH, BATCH, STEP, MOMENTUM)
-                        s += 1
+            while s < n:
+                b = (first_batch + s) % N_BATCHES
+                if graphed is not None and not eager and b == 0 and n - s >= N_BATCHES:
+                    graphed.replay()
+                    s += N_BATCHES
+                else:
+                    stepper.step(b * BATCH, BATCH, STEP, MOMENTUM)
+                    s += 1
 
     run(0, W)
     barrier()
     t0 = time.perf_counter()
-    run(0 if dist is not None else W, K)  # data parallel: start on a graph boundary (64 resident batches)
+    run(0 if dist is not None else W, K)  # data parallel: start on a graph boundary (the resident batches)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -176,19 +341,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- dominant-kernel roofline: HIP events on the kernel's own stream, over the same step loop
+    # ---- per-kernel roofline: the dispatches' own begin/end timestamps, over the same step loop
     roofline = None
     cpu = None
+    host_rate = None
     # The kernel-timing pass steps the net again. On the data-parallel path a step contains a
     # collective, so EVERY rank takes part (eagerly: kernels inside a replayed graph are not
     # timed); only rank 0 records and reports.
     nt = min(K, 1000) if dist is None else min(K, 256)
     if rank == 0:
         net.timing_enable(True)
-    if dist is None:
-        run(W + K, nt)
-    else:
-        run(K, nt, eager=True)
+    run(W + K if dist is None else K, nt, eager=True)
     barrier()
     if rank == 0:
         fwd_us, fwd_n = net.timing_read(0)
@@ -197,51 +360,81 @@ def main():
         net.timing_enable(False)
         P_all = sum(DIMS[l] * DIMS[l + 1] for l in range(len(DIMS) - 1))
         P_mid = P_all - DIMS[0] * DIMS[1]
-        e4 = 4  # bytes per element (f32)
-        # algorithmic work per launch (SURVEY 8d accounting):
+        eo = 2 if bf16 else 4  # bytes per GEMM operand element
+        mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+        # algorithmic work per launch (SURVEY 8d accounting), f32 masters throughout:
         #   fwd_first : 2*B*d0*d1 FLOP; reads A_0 (B*d0) + W_0 (d0*d1), writes A_1 (B*d1)
         #   middle    : 2*B*2*(P - d0 d1) FLOP; reads W_1.. once per use (fwd + bwd), A_1, Y; writes A_2.., delta_1..
-        #   grad      : 2*B*P FLOP; reads A_l, delta_{l+1} for every layer and W, V (2P); writes W, V (2P)
+        #   grad      : 2*B*P FLOP; reads A_l, delta_{l+1} for every layer and W, V (2P f32); writes W, V (2P f32)
         #   (data-parallel path: the same kernel stores G instead -- P written, W and V untouched;
         #    the update is sgd_momentum_kernel after the all-reduce)
-        dp = dist is not None
-        grad_name = "grad_update(all layers, 784x300xB + ..., stores G; update after the all-reduce)" if dp \
-            else "grad_update(all layers, 784x300xB + ...)"
+        is_dp = dist is not None
+        names = {"fwd": "fwd_first(128x784x300)", "mid": "middle(fwd L2.. + softmax + bwd-data)",
+                 "grad": "grad_update(all layers, 784x300xB + ...%s)" % (", stores G; update after the all-reduce" if is_dp else "")}
+        pmc_key = {"fwd": "fwd_first", "mid": "middle4", "grad": "grad_update"}
         kernels = {
-            "fwd_first(128x784x300)": (fwd_us, 2.0 * BATCH * DIMS[0] * DIMS[1],
-                                       e4 * (BATCH * DIMS[0] + DIMS[0] * DIMS[1] + BATCH * DIMS[1])),
-            "middle(fwd L2.. + softmax + bwd-data)": (mid_us, 2.0 * BATCH * 2 * P_mid,
-                                                      e4 * (2 * P_mid + BATCH * (DIMS[1] + 2 * DIMS[-1] + 2 * sum(DIMS[1:])))),
-            grad_name: (grad_us, 2.0 * BATCH * P_all,
-                        e4 * ((1 if dp else 4) * P_all + BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:])))),
+            "fwd": (fwd_us, fwd_n, 2.0 * BATCH * DIMS[0] * DIMS[1],
+                    eo * (BATCH * DIMS[0] + DIMS[0] * DIMS[1]) + eo * BATCH * DIMS[1]),
+            "mid": (mid_us, mid_n, 2.0 * BATCH * 2 * P_mid,
+                    eo * 2 * P_mid + eo * BATCH * (DIMS[1] + 2 * sum(DIMS[1:])) + 4 * BATCH * 2 * DIMS[-1]),
+            "grad": (grad_us, grad_n, 2.0 * BATCH * P_all,
+                     4 * (1 if is_dp else 4) * P_all + eo * BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:]))),
         }
+        kernels = {k: v for k, v in kernels.items() if v[1] > 0 and v[0] > 0}
         step_us = dt / K * 1e6
-        # roofline kernel: the one that moves the most bytes and FLOPs -- every layer's G = A^T.delta
-        # with the momentum update fused.  Its arithmetic intensity (13 FLOP/B) is below the f32
-        # ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B), so the bound that applies is HBM.
-        name = grad_name
-        us, flop, nbytes = kernels[name]
-        ach = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None if dp else pmc_traffic("grad_update_kernel<true"),
-                    "avg_launch_us": round(us, 3), "launches": grad_n,
-                    "algorithmic_bytes_per_launch": nbytes, "flop_per_launch": flop,
-                    "arithmetic_intensity_flop_per_byte": round(flop / nbytes, 2),
-                    "mfma_frac": round(flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if us > 0 else None,
-                    # SURVEY 8d, whole step: 6P - 2 d0 d1 FLOP per sample; bytes = weights (P + (P - d0 d1) + P + 5P)
-                    # + activations B (d0 + 4 sum_{l>=1} d_l), 4 B each
-                    "whole_step": {"flop": (6 * P_all - 2 * DIMS[0] * DIMS[1]) * BATCH,
-                                   "algorithmic_bytes": e4 * (8 * P_all - DIMS[0] * DIMS[1] + BATCH * (DIMS[0] + 4 * sum(DIMS[1:]))),
-                                   "us": round(step_us, 3),
-                                   "mfma_frac": round((6 * P_all - 2 * DIMS[0] * DIMS[1]) * BATCH / (step_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                                   "hbm_frac": round(e4 * (8 * P_all - DIMS[0] * DIMS[1] + BATCH * (DIMS[0] + 4 * sum(DIMS[1:]))) / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
-                    "other": {k: {"avg_us": round(v[0], 3), "flop": v[1], "algorithmic_bytes": v[2],
-                                  "tflops": round(v[1] / (v[0] * 1e-6) / 1e12, 3) if v[0] > 0 else None,
-                                  "gbs": round(v[2] / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else None,
-                                  "share_of_step": round(v[0] / step_us, 3)} for k, v in kernels.items()}}
-        if dist is None and not args.no_cpu_baseline:
-            cpu = cpu_baseline()
+        whole_flop = (6 * P_all - 2 * DIMS[0] * DIMS[1]) * BATCH
+        whole_bytes = 4 * (8 * P_all - DIMS[0] * DIMS[1] + BATCH * (DIMS[0] + 4 * sum(DIMS[1:])))
+
+        def entry(k):
+            us, n, flop, nbytes = kernels[k]
+            return {"name": names[k], "avg_us": round(us, 3), "launches": n, "flop": flop, "algorithmic_bytes": nbytes,
+                    "tflops": round(flop / (us * 1e-6) / 1e12, 3), "gbs": round(nbytes / (us * 1e-6) / 1e9, 1),
+                    "mfma_frac": round(flop / (us * 1e-6) / 1e12 / mfma_peak, 4),
+                    "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                    "share_of_step": round(us / step_us, 3),
+                    "traffic": None if is_dp or bf16 else pmc_traffic(pmc_key[k])}
+        if kernels:
+            # roofline kernel = the one with the largest share of the step's time.  Which roof: its
+            # arithmetic intensity against the ridge of this dtype (peak FLOP/s / 8 TB/s).
+            dom = max(kernels, key=lambda k: kernels[k][0])
+            e = entry(dom)
+            ai = e["flop"] / e["algorithmic_bytes"]
+            ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+            if ai >= ridge:
+                bound, ach, peak, unit = "mfma", e["tflops"], mfma_peak, "TFLOP/s"
+            else:
+                bound, ach, peak, unit = "hbm", e["gbs"], HBM_PEAK_GBS, "GB/s"
+            roofline = {"bound": bound, "kernel": e["name"], "achieved": ach, "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 4), "traffic": e["traffic"],
+                        "traffic_source": PMC_FILE if e["traffic"] is not None else None,
+                        "avg_launch_us": e["avg_us"], "launches": e["launches"],
+                        "algorithmic_bytes_per_launch": e["algorithmic_bytes"], "flop_per_launch": e["flop"],
+                        "arithmetic_intensity_flop_per_byte": round(ai, 2), "ridge_flop_per_byte": round(ridge, 1),
+                        "share_of_step": e["share_of_step"],
+                        "limiter": "launch + memory latency and instruction issue, not bandwidth or MFMA rate: the launch moves "
+                                   "<1 MB and <0.1 GFLOP (DESIGN.md 3.3)",
+                        "gemm_784x300_mfma_frac": entry("fwd")["mfma_frac"] if "fwd" in kernels else None,
+                        # SURVEY 8d, whole step: 6P - 2 d0 d1 FLOP per sample; bytes = weights (P + (P - d0 d1) + P + 5P)
+                        # + activations B (d0 + 4 sum_{l>=1} d_l), 4 B each
+                        "whole_step": {"flop": whole_flop, "algorithmic_bytes": whole_bytes, "us": round(step_us, 3),
+                                       "mfma_frac": round(whole_flop / (step_us * 1e-6) / 1e12 / mfma_peak, 4),
+                                       "hbm_frac": round(whole_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                        "other": {names[k]: entry(k) for k in kernels if k != dom}}
+        if dist is None:
+            # PCIe-inclusive rate of the literal NeuralNet.gradientStep(double[] rows) call shape: fp64 host
+            # batch -> pageable H2D -> convert -> step.  Reported beside `value`, never as `value`.
+            nh = 200
+            for s in range(20):
+                net.gradientStep(X[:BATCH], STEP, MOMENTUM, False, expected=Y[:BATCH])
+            net.synchronize()
+            th = time.perf_counter()
+            for s in range(nh):
+                r = (s % N_BATCHES) * BATCH
+                net.gradientStep(X[r:r + BATCH], STEP, MOMENTUM, False, expected=Y[r:r + BATCH])
+            net.synchronize()
+            host_rate = round(nh * BATCH / (time.perf_counter() - th), 1)
+            if not args.no_cpu_baseline:
+                cpu = cpu_baseline()
 
     lockstep = None
     if dist is not None:
@@ -258,19 +451,34 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "784-300-100-10 SoftmaxCrossEntropyNeuralNet gradientStep, fp32, "
-                                   "batch 128 per GPU (BASELINE configs[1])",
+            "dtype": args.dtype, "data": "synthetic",
+            "host_batch_samples_per_s": host_rate,
+            "config": {"workload": "784-300-100-10 SoftmaxCrossEntropyNeuralNet gradientStep, %s, batch 128 per GPU "
+                                   "(BASELINE configs[%d])" % ("bf16 GEMM operands / f32 accumulate and masters", 2) if bf16 else
+                                   "784-300-100-10 SoftmaxCrossEntropyNeuralNet gradientStep, fp32, batch 128 per GPU "
+                                   "(BASELINE configs[1])",
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
-                       "dp_mode": (None if dist is None else ("hipGraph replay of 64 steps" if graphed is not None else "eager")),
+                       "backend": None if dist is None else ("rccl" if args.backend == "nccl" else args.backend),
+                       "world_size": None if dist is None else stepper.world,
+                       "dp_mode": (None if dist is None else
+                                   ("hipGraph replay of %d steps" % N_BATCHES if graphed is not None else "eager")),
                        "dp_replicas_identical": lockstep,
                        "step": STEP, "momentum": MOMENTUM, "inner_activation": "leaky_relu"},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        sys.stdout.flush()
-        os.dup2(stdout_fd, 1)
-        print(json.dumps(line), flush=True)
+        emit(json.dumps(line))
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(launch(args, argv))       # nothing GPU-related has been imported in this process
+    if world_env is not None and int(world_env) != args.gpus:
+        args.gpus = int(world_env)
+    worker(args, argv)
 
 
 if __name__ == "__main__":

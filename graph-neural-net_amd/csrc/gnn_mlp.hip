@@ -93,13 +93,49 @@ struct gnn_mlp {
     int64_t tr_first_batch = -1; int tr_B = 0; int64_t tr_nb = 0; double tr_step = 0, tr_mom = 0;
     const float *tr_dx = nullptr;
 
+    hipError_t launch_error = hipSuccess; // first refused launch of a module / function-pointer kernel since the last check
     const int32_t *cur_idx = nullptr; // device row indices of the batch being stepped (fused path reads rows through them)
 
     bool timing = false;
     TimerClass timers[4];
+
+    // development / test switches, read ONCE at create (never on the step path)
+    int env_path = 0;          // GNN_MLP_PATH: 0 default, 1 "generic", 2 "nomid4"
+    int env_hybrid = -1;       // GNN_MLP_HYBRID: -1 unset, else bit 0 = fwd_first, bit 1 = grad_update
+    bool env_tail_off = false; // GNN_MLP_TAIL=0: the three-launch form instead of tail_kernel
+    bool env_graph = false;    // GNN_MLP_GRAPH=1: train_range replays a captured pass
+    bool env_jit_off = false;  // GNN_MLP_JIT=0
+    bool env_static_off = false; // GNN_MLP_STATIC=0
 };
 
 namespace {
+
+void read_env(gnn_mlp *h) {
+    auto is = [](const char *name, const char *val) { const char *e = getenv(name); return e && !strcmp(e, val); };
+    h->env_path = is("GNN_MLP_PATH", "generic") ? 1 : is("GNN_MLP_PATH", "nomid4") ? 2 : 0;
+    const char *hy = getenv("GNN_MLP_HYBRID");
+    h->env_hybrid = hy ? (atoi(hy) & 3) : -1;
+    h->env_tail_off = is("GNN_MLP_TAIL", "0");
+    h->env_graph = is("GNN_MLP_GRAPH", "1");
+    h->env_jit_off = is("GNN_MLP_JIT", "0");
+    h->env_static_off = is("GNN_MLP_STATIC", "0");
+}
+
+// every launch since the last check was accepted: the runtime's sticky error and the return codes of
+// the kernels launched through function pointers / hiprtc modules (fused_forward)
+int check_launches(gnn_mlp *h) {
+    const hipError_t sticky = hipGetLastError();
+    const hipError_t mine = h->launch_error;
+    h->launch_error = hipSuccess;
+    if (mine != hipSuccess) return fail(GNN_ERR_HIP, std::string("kernel launch refused: ") + hipGetErrorString(mine));
+    if (sticky != hipSuccess) return fail(GNN_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(sticky));
+    return GNN_OK;
+}
+#define TRY_LAUNCHES(h)                 \
+    do {                                \
+        int rc_ = check_launches(h);    \
+        if (rc_ != GNN_OK) return rc_;  \
+    } while (0)
 
 int check_handle(const gnn_mlp *h) {
     if (!h) return fail(GNN_ERR_BAD_ARG, "null handle");
@@ -288,8 +324,7 @@ void plan_fused(gnn_mlp *h) {
     h->fused = false;
     h->mid4 = false;
     h->mid_generic = false;
-    const char *env = getenv("GNN_MLP_PATH");
-    if (env && !strcmp(env, "generic")) return;
+    if (h->env_path == 1) return;
     if (h->dtype != GNN_DTYPE_F32) return; // bf16 operands: generic per-layer GEMMs (gemm_bf16.h)
     const int L = h->L, Lm = L - 1;
     if (L < 3 || L > MAX_LAYERS) return;
@@ -357,8 +392,7 @@ template <class SH> bool shape_matches(const gnn_mlp *h) {
 }
 
 const void *mid4_function(const gnn_mlp *h, bool bwd) {
-    const char *env = getenv("GNN_MLP_STATIC");
-    const bool allow_static = !(env && !strcmp(env, "0"));
+    const bool allow_static = !h->env_static_off;
     if (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE) {
         if (shape_matches<ShapeMnistA>(h)) return mid4_fn_sh<ShapeMnistA, 0>(h->inner_act, bwd);
         if (shape_matches<ShapeMnistB>(h)) return mid4_fn_sh<ShapeMnistB, 0>(h->inner_act, bwd);
@@ -381,8 +415,7 @@ const void *mid4_function(const gnn_mlp *h, bool bwd) {
 
 void plan_mid4(gnn_mlp *h) {
     h->mid4 = false;
-    const char *env = getenv("GNN_MLP_PATH");
-    if (env && !strcmp(env, "nomid4")) return; // tests: force the per-layer middle
+    if (h->env_path == 2) return; // tests: force the per-layer middle
     const int L = h->L, Lm = L - 1;
     Mid4Params &m = h->mid4p;
     m = Mid4Params{};
@@ -394,8 +427,7 @@ void plan_mid4(gnn_mlp *h) {
     m.last_act = h->last_act;
     m.inner_act = h->inner_act;
     {
-        const char *senv = getenv("GNN_MLP_STATIC");
-        const bool allow_static = !(senv && !strcmp(senv, "0"));
+        const bool allow_static = !h->env_static_off;
         h->specialization = (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE &&
                              (shape_matches<ShapeMnistA>(h) || shape_matches<ShapeMnistB>(h))) ? 1 : 0;
     }
@@ -415,8 +447,7 @@ void plan_mid4(gnn_mlp *h) {
 void try_specialize(gnn_mlp *h) {
     if (!h->mid4 || h->specialization != 0 || h->jit_tried) return;
     h->jit_tried = true;
-    const char *env = getenv("GNN_MLP_JIT");
-    if (env && !strcmp(env, "0")) return;
+    if (h->env_jit_off) return;
     const jit::Specialised *sp = jit::get_middle4(h->device, h->dims.data(), h->L, h->inner_act, h->out_kind, h->mid4_lds_bytes);
     if (!sp) return;
     h->mid4_jit[0] = sp->fn[0];
@@ -488,15 +519,18 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
             }
             if (tc.used < tc.start.size()) { ev0 = tc.start[tc.used]; ev1 = tc.stop[tc.used]; tc.used++; }
         }
+        hipError_t le;
         if (h->mid4_jit[bw]) { // module function: global size is given in threads
-            (void)hipExtModuleLaunchKernel(h->mid4_jit[bw], grid * 1024u, 1, 1, 1024, 1, 1, h->mid4_lds_bytes, h->stream, args,
-                                           nullptr, ev0, ev1, 0);
+            le = hipExtModuleLaunchKernel(h->mid4_jit[bw], grid * 1024u, 1, 1, 1024, 1, 1, h->mid4_lds_bytes, h->stream, args,
+                                          nullptr, ev0, ev1, 0);
         } else if (ev0) {
-            (void)hipExtLaunchKernel(const_cast<void *>(h->mid4_fn[bw]), dim3(grid), dim3(1024), args, h->mid4_lds_bytes,
-                                     h->stream, ev0, ev1, 0);
+            le = hipExtLaunchKernel(const_cast<void *>(h->mid4_fn[bw]), dim3(grid), dim3(1024), args, h->mid4_lds_bytes,
+                                    h->stream, ev0, ev1, 0);
         } else {
-            (void)hipLaunchKernel(h->mid4_fn[bw], dim3(grid), dim3(1024), args, h->mid4_lds_bytes, h->stream);
+            le = hipLaunchKernel(h->mid4_fn[bw], dim3(grid), dim3(1024), args, h->mid4_lds_bytes, h->stream);
         }
+        // a refused launch must not pass for a step: callers read it back through hipGetLastError / launch_error
+        if (le != hipSuccess && h->launch_error == hipSuccess) h->launch_error = le;
     }
 }
 
@@ -526,8 +560,7 @@ void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float
 struct HybridChoice { bool first, grad; };
 HybridChoice hybrid_choice(const gnn_mlp *h, int B) {
     HybridChoice c{true, true};
-    const char *env = getenv("GNN_MLP_HYBRID"); // tests/development: bit 0 = fwd_first, bit 1 = grad_update
-    if (env) { const int m = atoi(env); c.first = (m & 1) != 0; c.grad = (m & 2) != 0; return c; }
+    if (h->env_hybrid >= 0) { c.first = (h->env_hybrid & 1) != 0; c.grad = (h->env_hybrid & 2) != 0; return c; } // tests/development
     const int B_pad = pad_up(B);
     c.first = pick_tile(B_pad, h->ld[1]) == 32;
     int64_t big = 0, all = 0; // gradient elements in layers whose GEMM grid would fill the chip on its own
@@ -542,9 +575,7 @@ HybridChoice hybrid_choice(const gnn_mlp *h, int B) {
 
 // Nets with at most 16 outputs, off the row-block path: last layer + output rule (+ delta_{L-2}) in one launch
 bool use_tail(const gnn_mlp *h) {
-    const char *env = getenv("GNN_MLP_TAIL"); // tests: "0" = the three-launch form
-    const bool off = env && !strcmp(env, "0");
-    return !off && h->dtype == GNN_DTYPE_F32 && h->out_kind == GNN_OUT_SOFTMAX_CE && h->ld[h->L - 1] == 16;
+    return !h->env_tail_off && h->dtype == GNN_DTYPE_F32 && h->out_kind == GNN_OUT_SOFTMAX_CE && h->ld[h->L - 1] == 16;
 }
 void launch_tail(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob, bool want_loss, bool want_label) {
     const int Lm = h->L - 1;
@@ -645,7 +676,7 @@ int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step
     ScopedTimer tm(h, GNN_K_STEP);
     do_gradient(h, a0, y, B, true, (float)(step / (double)B), (float)momentum);
     h->time++;
-    HIP_TRY(hipGetLastError());
+    TRY_LAUNCHES(h);
     return GNN_OK;
 }
 
@@ -695,6 +726,17 @@ template <typename T> int dev_alloc(T **p, size_t n, hipStream_t s) {
     return GNN_OK;
 }
 
+// scratch device allocation released on every exit path
+struct DevScratch {
+    void *p = nullptr;
+    ~DevScratch() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        HIP_TRY(hipMalloc(&p, bytes ? bytes : 1));
+        return GNN_OK;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
 #define TRY(expr)                      \
     do {                               \
         int rc_ = (expr);              \
@@ -737,6 +779,7 @@ int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act,
     h->out_kind = out_kind; h->inner_act = inner_act; h->last_act = last_act; h->loss = loss; h->dtype = dtype;
     h->max_batch = max_batch;
     h->cap_rows = pad_up(max_batch);
+    read_env(h);
     h->w_off.resize(n_dims - 1);
     size_t off = 0;
     for (int l = 0; l < n_dims - 1; l++) {
@@ -828,7 +871,7 @@ int gnn_mlp_propagate(gnn_mlp_t *h, const double *X, int B, double *out) {
     TRY(check_batch(h, B));
     TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
     do_forward(h, h->act[0], nullptr, B, true, false, false);
-    HIP_TRY(hipGetLastError());
+    TRY_LAUNCHES(h);
     return export_rows(h, h->prob, h->ld[h->L - 1], h->dims[h->L - 1], B, out);
 }
 
@@ -853,7 +896,7 @@ int gnn_mlp_loss(gnn_mlp_t *h, const double *X, const double *Y, int B, double *
     TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
     TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
     do_forward(h, h->act[0], h->ybuf, B, false, true, false);
-    HIP_TRY(hipGetLastError());
+    TRY_LAUNCHES(h);
     return read_loss(h, B, loss_per_sample);
 }
 
@@ -863,7 +906,7 @@ int gnn_mlp_argmax(gnn_mlp_t *h, const double *X, int B, int32_t *labels) {
     TRY(check_batch(h, B));
     TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
     do_forward(h, h->act[0], nullptr, B, false, false, true);
-    HIP_TRY(hipGetLastError());
+    TRY_LAUNCHES(h);
     return read_labels(h, B, labels);
 }
 
@@ -875,7 +918,7 @@ int gnn_mlp_compute_gradient(gnn_mlp_t *h, const double *X, const double *Y, int
     TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
     TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
     do_gradient(h, h->act[0], h->ybuf, B, false, 0.f, 0.f);
-    HIP_TRY(hipGetLastError());
+    TRY_LAUNCHES(h);
     return GNN_OK;
 }
 
@@ -906,6 +949,23 @@ int gnn_mlp_get_momentum(gnn_mlp_t *h, double *flat) { TRY(check_handle(h)); ret
 int gnn_mlp_set_momentum(gnn_mlp_t *h, const double *flat) { TRY(check_handle(h)); return set_flat(h, h->V, flat); }
 
 // ---- checkpoint -----------------------------------------------------------------------------
+// File (little endian): "GNNMLP2\0", int32 L, int32 dims[L], int32 out_kind, inner_act, last_act, loss,
+// dtype, int32 time, int64 n_params, fp64 weights[P], fp64 momentum[P], uint64 FNV-1a of every byte
+// before it.  A file written for another net (dims OR any of the five enums) is refused, and so is a
+// truncated or altered one.
+namespace {
+struct Fnv {
+    uint64_t h = 1469598103934665603ull;
+    void add(const void *p, size_t n) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    }
+};
+bool put(FILE *f, Fnv &c, const void *p, size_t n) { c.add(p, n); return fwrite(p, 1, n, f) == n; }
+bool get(FILE *f, Fnv &c, void *p, size_t n) { if (fread(p, 1, n, f) != n) return false; c.add(p, n); return true; }
+const char kCkptMagic[8] = {'G', 'N', 'N', 'M', 'L', 'P', '2', 0};
+} // namespace
+
 int gnn_mlp_save_checkpoint(gnn_mlp_t *h, const char *path) {
     TRY(check_handle(h));
     if (!path) return fail(GNN_ERR_BAD_ARG, "null path");
@@ -914,12 +974,16 @@ int gnn_mlp_save_checkpoint(gnn_mlp_t *h, const char *path) {
     TRY(get_flat(h, h->V, v.data()));
     FILE *f = fopen(path, "wb");
     if (!f) return fail(GNN_ERR_BAD_ARG, std::string("cannot open ") + path);
-    const char magic[8] = {'G', 'N', 'N', 'M', 'L', 'P', '1', 0};
-    const int32_t L = h->L, tm = h->time;
-    bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(&L, 4, 1, f) == 1;
-    for (int l = 0; ok && l < L; l++) { const int32_t d = h->dims[l]; ok = fwrite(&d, 4, 1, f) == 1; }
-    ok = ok && fwrite(&tm, 4, 1, f) == 1 && fwrite(w.data(), 8, w.size(), f) == w.size() &&
-         fwrite(v.data(), 8, v.size(), f) == v.size();
+    Fnv c;
+    const int32_t L = h->L;
+    bool ok = put(f, c, kCkptMagic, 8) && put(f, c, &L, 4);
+    for (int l = 0; ok && l < L; l++) { const int32_t d = h->dims[l]; ok = put(f, c, &d, 4); }
+    const int32_t cfg[6] = {h->out_kind, h->inner_act, h->last_act, h->loss, h->dtype, h->time};
+    const int64_t np = h->n_params;
+    ok = ok && put(f, c, cfg, sizeof cfg) && put(f, c, &np, 8) && put(f, c, w.data(), 8 * w.size()) &&
+         put(f, c, v.data(), 8 * v.size());
+    const uint64_t sum = c.h;
+    ok = ok && fwrite(&sum, 8, 1, f) == 1;
     ok = (fclose(f) == 0) && ok;
     return ok ? GNN_OK : fail(GNN_ERR_BAD_ARG, std::string("short write to ") + path);
 }
@@ -929,18 +993,41 @@ int gnn_mlp_load_checkpoint(gnn_mlp_t *h, const char *path) {
     if (!path) return fail(GNN_ERR_BAD_ARG, "null path");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(GNN_ERR_BAD_ARG, std::string("cannot open ") + path);
+    Fnv c;
     char magic[8];
-    int32_t L = 0, tm = 0;
-    bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, "GNNMLP1", 8) && fread(&L, 4, 1, f) == 1 && L == h->L;
-    for (int l = 0; ok && l < L; l++) { int32_t d = 0; ok = fread(&d, 4, 1, f) == 1 && d == h->dims[l]; }
-    std::vector<double> w((size_t)h->n_params), v((size_t)h->n_params);
-    ok = ok && fread(&tm, 4, 1, f) == 1 && tm >= 0 && fread(w.data(), 8, w.size(), f) == w.size() &&
-         fread(v.data(), 8, v.size(), f) == v.size();
+    int32_t L = 0, cfg[6] = {0, 0, 0, 0, 0, 0};
+    int64_t np = 0;
+    const char *why = nullptr;
+    bool ok = get(f, c, magic, 8) && !memcmp(magic, kCkptMagic, 8) && get(f, c, &L, 4);
+    if (!ok) why = "not a GNNMLP2 checkpoint";
+    if (ok && L != h->L) { ok = false; why = "layer count differs"; }
+    for (int l = 0; ok && l < L; l++) {
+        int32_t d = 0;
+        ok = get(f, c, &d, 4);
+        if (ok && d != h->dims[l]) { ok = false; why = "layer dimensions differ"; }
+    }
+    if (ok) {
+        ok = get(f, c, cfg, sizeof cfg) && get(f, c, &np, 8);
+        if (!ok) why = "truncated header";
+        else if (cfg[0] != h->out_kind || cfg[1] != h->inner_act || cfg[4] != h->dtype ||
+                 (h->out_kind == GNN_OUT_ACT_LOSS && (cfg[2] != h->last_act || cfg[3] != h->loss))) {
+            ok = false; why = "net configuration differs (output kind / activations / loss / dtype)";
+        } else if (np != h->n_params || cfg[5] < 0) { ok = false; why = "parameter count differs"; }
+    }
+    std::vector<double> w, v;
+    if (ok) {
+        w.resize((size_t)h->n_params); v.resize((size_t)h->n_params);
+        uint64_t sum = 0;
+        ok = get(f, c, w.data(), 8 * w.size()) && get(f, c, v.data(), 8 * v.size());
+        const uint64_t want = c.h;
+        ok = ok && fread(&sum, 8, 1, f) == 1 && sum == want && fgetc(f) == EOF;
+        if (!ok) why = "payload truncated, altered or followed by extra bytes (checksum)";
+    }
     fclose(f);
-    if (!ok) return fail(GNN_ERR_BAD_ARG, std::string(path) + ": not a checkpoint of this net");
+    if (!ok) return fail(GNN_ERR_BAD_ARG, std::string(path) + ": " + (why ? why : "not a checkpoint of this net"));
     TRY(set_flat(h, h->W, w.data()));
     TRY(set_flat(h, h->V, v.data()));
-    h->time = tm;
+    h->time = cfg[5];
     return GNN_OK;
 }
 
@@ -962,9 +1049,10 @@ int gnn_mlp_upload_dataset(gnn_mlp_t *h, const double *X, const double *Y, int64
     TRY(alloc_dataset(h, N));
     const int d0 = h->dims[0], dl = h->dims[h->L - 1];
     const int64_t chunk = 4096;
-    double *sx = nullptr, *sy = nullptr;
-    HIP_TRY(hipMalloc((void **)&sx, sizeof(double) * chunk * d0));
-    HIP_TRY(hipMalloc((void **)&sy, sizeof(double) * chunk * dl));
+    DevScratch bx, by;
+    TRY(bx.alloc(sizeof(double) * chunk * d0));
+    TRY(by.alloc(sizeof(double) * chunk * dl));
+    double *sx = bx.as<double>(), *sy = by.as<double>();
     hipError_t err = hipSuccess;
     for (int64_t r0 = 0; r0 < N && err == hipSuccess; r0 += chunk) {
         const int64_t n = (N - r0 < chunk) ? N - r0 : chunk;
@@ -978,12 +1066,8 @@ int gnn_mlp_upload_dataset(gnn_mlp_t *h, const double *X, const double *Y, int64
                            dl, h->DY + (size_t)r0 * h->ld[h->L - 1], h->ld[h->L - 1], n, n, 0, 0);
         err = hipStreamSynchronize(h->stream); // the staging buffers are reused by the next chunk
     }
-    if (err != hipSuccess) {
-        (void)hipFree(sx); (void)hipFree(sy);
-        return fail(GNN_ERR_HIP, std::string("dataset upload: ") + hipGetErrorString(err));
-    }
-    (void)hipFree(sx); (void)hipFree(sy);
-    HIP_TRY(hipGetLastError());
+    if (err != hipSuccess) return fail(GNN_ERR_HIP, std::string("dataset upload: ") + hipGetErrorString(err));
+    TRY_LAUNCHES(h);
     h->dataset_n = N;
     return GNN_OK;
 }
@@ -993,18 +1077,18 @@ int gnn_mlp_upload_dataset_u8(gnn_mlp_t *h, const uint8_t *pixels, const uint8_t
     if (!pixels || !labels || N <= 0) return fail(GNN_ERR_BAD_ARG, "bad dataset");
     TRY(alloc_dataset(h, N));
     const int d0 = h->dims[0], dl = h->dims[h->L - 1];
-    uint8_t *sp = nullptr, *sl = nullptr;
-    HIP_TRY(hipMalloc((void **)&sp, (size_t)N * d0));
-    HIP_TRY(hipMalloc((void **)&sl, (size_t)N));
+    DevScratch bp, bl;
+    TRY(bp.alloc((size_t)N * d0));
+    TRY(bl.alloc((size_t)N));
+    uint8_t *sp = bp.as<uint8_t>(), *sl = bl.as<uint8_t>();
     HIP_TRY(hipMemcpyAsync(sp, pixels, (size_t)N * d0, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(sl, labels, (size_t)N, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(encode_u8_kernel, dim3(grid_for(N * h->ld[0])), dim3(256), 0, h->stream, sp, d0, h->DX, h->ld[0],
                        N, N, h->inner_act);
     hipLaunchKernelGGL(onehot_u8_kernel, dim3(grid_for(N * h->ld[h->L - 1])), dim3(256), 0, h->stream, sl, dl, h->DY,
                        h->ld[h->L - 1], N, N);
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    (void)hipFree(sp); (void)hipFree(sl);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream)); // the scratch buffers are released when this function returns
+    TRY_LAUNCHES(h);
     h->dataset_n = N;
     return GNN_OK;
 }
@@ -1040,8 +1124,7 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
     // already run back to back) while the capture costs a few ms on the first call.  Never while
     // per-kernel timing is on (timed launches carry events) or on a caller-provided stream (the
     // caller may be capturing itself).
-    const char *genv = getenv("GNN_MLP_GRAPH");
-    const bool want_graph = genv && !strcmp(genv, "1") && !h->timing && h->stream == h->own_stream &&
+    const bool want_graph = h->env_graph && !h->timing && h->stream == h->own_stream &&
                             nb >= 2 && nb <= 1024 && n_steps >= 2 * nb;
     if (want_graph) {
         const int64_t fb = (first / B) % nb;
@@ -1112,7 +1195,7 @@ int gnn_mlp_loss_range(gnn_mlp_t *h, int64_t first, int B, double *loss_per_samp
     TRY(check_batch(h, B));
     TRY(check_range(h, first, B));
     do_forward(h, h->DX + (size_t)first * h->ld[0], h->DY + (size_t)first * h->ld[h->L - 1], B, false, true, false);
-    HIP_TRY(hipGetLastError());
+    TRY_LAUNCHES(h);
     return read_loss(h, B, loss_per_sample);
 }
 
@@ -1122,7 +1205,7 @@ int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels) {
     TRY(check_batch(h, B));
     TRY(check_range(h, first, B));
     do_forward(h, h->DX + (size_t)first * h->ld[0], nullptr, B, false, false, true);
-    HIP_TRY(hipGetLastError());
+    TRY_LAUNCHES(h);
     return read_labels(h, B, labels);
 }
 
@@ -1285,7 +1368,7 @@ int gnn_mlp_compute_gradient_range(gnn_mlp_t *h, int64_t first, int B) {
     const float *a0 = h->DX + (size_t)first * h->ld[0];
     maybe_specialize(h);
     do_gradient(h, a0, h->DY + (size_t)first * h->ld[h->L - 1], B, false, 0.f, 0.f);
-    HIP_TRY(hipGetLastError());
+    TRY_LAUNCHES(h);
     return GNN_OK;
 }
 
@@ -1298,7 +1381,7 @@ int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentu
                        reinterpret_cast<float4 *>(h->W), reinterpret_cast<float4 *>(h->V),
                        reinterpret_cast<const float4 *>(h->G), n4, (float)(step / (double)B_global), (float)momentum);
     h->time++;
-    HIP_TRY(hipGetLastError());
+    TRY_LAUNCHES(h);
     return GNN_OK;
 }
 

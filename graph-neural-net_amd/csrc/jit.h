@@ -5,7 +5,7 @@
 // this problem size is worth 1.5x (10.6 vs 16 us for 784-300-100-10): a workgroup's critical
 // path is a few thousand instructions, and runtime extents mean kernarg loads, integer divisions
 // and loops with runtime bounds on that path.  Instead of enumerating shapes ahead of time, the
-// library keeps the kernel SOURCES (embedded at build time, _embedded_sources.h) and instantiates
+// library keeps the kernel SOURCES (embedded at build time, _generated/embedded_sources.h) and instantiates
 // the same template for the caller's layer sizes with hiprtc -- the MI355X-native replacement for
 // a tracing compiler: one explicit template instantiation, not a graph capture.
 // Failure at any point (no hiprtc, compile error, load error) is not an error of the path: the
@@ -21,7 +21,7 @@
 #include <string>
 #include <vector>
 
-#include "_embedded_sources.h"
+#include "_generated/embedded_sources.h" // written by build.py from the kernel headers
 
 namespace gnn {
 namespace jit {

@@ -15,7 +15,15 @@ The engine behind `DataParallelStep` is anything with
 `HipEngine` adapts a gnn_amd NeuralNet (the C ABI); tests drive the same class with a CPU
 engine over gloo.
 """
+import contextlib
+
 import numpy as np
+
+
+class CaptureFailed(RuntimeError):
+    """Stream capture of the step sequence did not produce a graph.  The stream that was being
+    captured is in the invalidated state; the process that holds it must not go on issuing GPU
+    work (bench.py exits and lets a fresh process run the eager path)."""
 
 
 def shard_rows(n_rows, rank, world):
@@ -36,9 +44,17 @@ class HipEngine:
         self.torch = torch
         self.grad_tensor = torch.zeros(net.grad_elems, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()  # the fill ran on torch's current stream; the kernels may use another
-        self.stream = stream if stream is not None else torch.cuda.current_stream()
+        # Kernels, collective and update must share ONE stream.  torch's default stream has the
+        # handle 0, which gnn_mlp_set_stream reads as "the handle's own (non-blocking) stream" --
+        # a stream torch.distributed knows nothing about -- so a side stream is always made here
+        # and DataParallelStep.step makes it torch's current stream around the collective.
+        self.stream = stream if stream is not None else torch.cuda.Stream()
         net.set_stream(self.stream.cuda_stream)
         net.bind_grad_buffer(self.grad_tensor.data_ptr(), self.grad_tensor.numel())
+
+    def stream_context(self):
+        """Makes the engine's stream torch's current stream (the collective is enqueued on it)."""
+        return self.torch.cuda.stream(self.stream)
 
     def rebind_stream(self, stream):
         """Move the net's kernels to another torch stream (after a capture that left the old one
@@ -67,13 +83,16 @@ class DataParallelStep:
         self.rank = dist_module.get_rank(group) if dist_module is not None else 0
 
     def step(self, first, B_local, step, momentum):
-        """One global gradientStep; every rank passes its own local rows."""
-        self.engine.compute_gradient_range(first, B_local)
-        B_global = B_local
-        if self.dist is not None and (self.world > 1 or self.always_reduce):
-            self.dist.all_reduce(self.engine.grad_tensor, op=self.dist.ReduceOp.SUM, group=self.group)
-            B_global = B_local * self.world
-        self.engine.apply_update(B_global, step, momentum)
+        """One global gradientStep; every rank passes its own local rows.  The three stages are
+        ordered by ONE stream: the engine's (CPU engines have none)."""
+        ctx = self.engine.stream_context() if hasattr(self.engine, "stream_context") else contextlib.nullcontext()
+        with ctx:
+            self.engine.compute_gradient_range(first, B_local)
+            B_global = B_local
+            if self.dist is not None and (self.world > 1 or self.always_reduce):
+                self.dist.all_reduce(self.engine.grad_tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+                B_global = B_local * self.world
+            self.engine.apply_update(B_global, step, momentum)
 
     def replicas_in_lockstep(self, torch_module, device="cpu"):
         """True when every rank holds the same weights (the all-reduce result is bitwise identical
@@ -94,7 +113,7 @@ class GraphedSteps:
     launch: the per-step host work (three ABI calls and one collective launch) disappears, which
     is what bounds a small-net step in eager mode.  Needs a HipEngine built on `stream`."""
 
-    def __init__(self, stepper, torch_module, stream, firsts, B_local, step, momentum):
+    def __init__(self, stepper, torch_module, stream, firsts, B_local, step, momentum, inject_failure=False):
         torch = torch_module
         self.stepper, self.torch, self.stream, self.n = stepper, torch, stream, len(firsts)
         self.graph = torch.cuda.CUDAGraph()
@@ -108,13 +127,15 @@ class GraphedSteps:
             with torch.cuda.graph(self.graph, stream=stream):
                 for f in firsts:
                     stepper.step(f, B_local, step, momentum)
-        except Exception:
-            # a collective that cannot be captured invalidates the capture: leave capture mode, drop
-            # the sticky HIP error and the steps that were only enqueued, so that the caller can go
-            # on with eager steps (bench.py does)
-            net.recover_stream()
+                if inject_failure:   # test hook: a call that is not permitted while capturing, so the capture really fails
+                    torch.cuda.synchronize()
+        except Exception as e:
+            # A collective (or anything else) that cannot be captured invalidates the capture.  On
+            # this ROCm the stream then stays invalidated and later HIP calls of the process crashed
+            # (round 1), so nothing is repaired here: only the host-side step counter is put back,
+            # and the caller is told to stop using this process for GPU work.
             net.advance_time(t_before - net.time)
-            raise
+            raise CaptureFailed("%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")) from e
         net.advance_time(-self.n)                 # the capture pass enqueued, it did not run
         self.eager_steps = self.n                 # steps really executed by the warm pass
 

@@ -121,9 +121,11 @@ int gnn_mlp_get_momentum(gnn_mlp_t *h, double *flat);
 int gnn_mlp_set_momentum(gnn_mlp_t *h, const double *flat);
 
 /* Checkpoint (the reference has no persistence at all: a trained net is lost at JVM exit,
- * SURVEY 5).  File = "GNNMLP1\0", int32 L, int32 dims[L], int32 time, fp64 weights[P],
- * fp64 momentum[P], little endian, flat layer-major row-major [in][out] like get_weights.
- * Loading requires identical dims. */
+ * SURVEY 5).  File, little endian: "GNNMLP2\0", int32 L, int32 dims[L], int32 out_kind, inner_act,
+ * last_act, loss, dtype, int32 time, int64 P, fp64 weights[P], fp64 momentum[P] (flat layer-major
+ * row-major [in][out] like get_weights), uint64 FNV-1a of all preceding bytes.  Loading requires
+ * identical dims AND configuration (a sigmoid / bf16 / GeneralNeuralNet file is refused by a
+ * leaky-ReLU / f32 / softmax net of the same dims) and an intact payload (length and checksum). */
 int gnn_mlp_save_checkpoint(gnn_mlp_t *h, const char *path);
 int gnn_mlp_load_checkpoint(gnn_mlp_t *h, const char *path);
 

@@ -12,43 +12,92 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "host_batch_samples_per_s"]
 
 
-def run_bench(*flags):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+def run_bench(*flags, want_stderr=False):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "128", "--warmup", "64",
-                          "--no-cpu-baseline", *flags], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
+                          "--no-cpu-baseline", *flags], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[:2000]
-    return json.loads(lines[0])
+    return (json.loads(lines[0]), out.stderr) if want_stderr else json.loads(lines[0])
 
 
-def check(line):
+def check(line, n_gpus=1, dtype="f32"):
     for k in KEYS:
         assert k in line, k
     assert line["metric"].startswith("training samples/sec") and line["unit"] == "samples/s"
-    assert line["steps"] == 128 and line["warmup"] == 64 and line["n_gpus"] == 1
+    assert line["steps"] == 128 and line["warmup"] == 64 and line["n_gpus"] == n_gpus
     assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
-    assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"]
-    assert abs(line["value"] - 128 * 128 / (line["ms_per_step"] * 1e-3 * 128)) <= 0.01 * line["value"]
+    assert line["dtype"] == dtype and line["data"] == "synthetic" and "workload" in line["config"]
+    assert line["config"]["global_batch"] == 128 * n_gpus
+    assert abs(line["value"] - n_gpus * 128 * 128 / (line["ms_per_step"] * 1e-3 * 128)) <= 0.01 * line["value"]
     r = line["roofline"]
-    for k in ["bound", "achieved", "peak", "unit", "frac", "traffic"]:
+    for k in ["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "share_of_step", "other"]:
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # the roofline kernel is the one with the largest share of the step
+    assert all(r["avg_launch_us"] >= o["avg_us"] for o in r["other"].values())
 
 
 def test_bench_line_single_process():
     line = run_bench()
     check(line)
     assert line["cpu_baseline"] is None          # --no-cpu-baseline
-    assert isinstance(line["roofline"]["traffic"], int)
+    assert line["roofline"]["traffic"] is None or isinstance(line["roofline"]["traffic"], int)
+    assert 0 < line["roofline"]["gemm_784x300_mfma_frac"] < 1
+    assert 0 < line["host_batch_samples_per_s"] < line["value"]   # PCIe-inclusive NeuralNet.gradientStep(double[]) rate
+
+
+def test_bench_line_bf16():
+    line = run_bench("--dtype", "bf16")
+    check(line, dtype="bf16")
+    assert "bf16" in line["config"]["workload"]
+
+
+def test_bench_two_ranks_self_launched():
+    """The driver's call shape at N > 1: `bench.py --gpus N` with no WORLD_SIZE.  bench.py starts the
+    ranks itself (here both on the one GPU, gloo carrying the all-reduce: numbers meaningless)."""
+    line = run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu")
+    check(line, n_gpus=2)
+    c = line["config"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and c["dp_mode"] == "eager"
+    assert c["dp_replicas_identical"] is True and c["parallelism"] == "dp2"
+
+
+def test_bench_capture_failure_hands_over_to_fresh_eager_ranks():
+    """A hipGraph capture that fails (here: a gloo collective, which cannot be captured, plus a
+    call that is not permitted while capturing) leaves the capturing stream invalidated; the ranks
+    must stop using the GPU and exit, and the eager run must come from FRESH processes."""
+    line, err = run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--inject-capture-failure", want_stderr=True)
+    check(line, n_gpus=2)
+    assert "hipGraph capture failed" in err and "starting fresh ranks in eager mode" in err
+    assert line["config"]["dp_mode"] == "eager" and line["config"]["dp_replicas_identical"] is True
 
 
 def test_bench_line_data_parallel_path():
     line = run_bench("--dp-path")
     check(line)
     assert line["config"]["dp_replicas_identical"] is True
-    assert line["config"]["dp_mode"] in ("hipGraph replay of 64 steps", "eager")
+    assert line["config"]["dp_mode"] == "hipGraph replay of 64 steps"   # RCCL (world 1) is capturable
+    assert line["config"]["backend"] == "rccl" and line["config"]["world_size"] == 1
+
+
+def test_bench_capture_failure_under_external_launcher():
+    """Started the way torch.distributed.run starts a rank (WORLD_SIZE in the environment, no launcher of
+    ours): a failed capture hands the eager run to the rank's own fresh child process."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env.pop("GNN_BENCH_LAUNCHER", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "128", "--warmup", "64",
+                          "--no-cpu-baseline", "--dp-path", "--inject-capture-failure"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    check(line)
+    assert "hipGraph capture failed" in out.stderr and line["config"]["dp_mode"] == "eager"

@@ -461,6 +461,61 @@ def test_train_range_graph_replay_equals_stepwise(gnn, monkeypatch):
     assert np.array_equal(a.get_momentum(), b.get_momentum())
 
 
+def test_config5_hipgraph_captured_step_equals_eager(gnn, monkeypatch):
+    """BASELINE configs[4] as stated: 784-1024-1024-1024-10, batch 256, hipGraph-captured train step.
+    Both capture routes -- gnn_mlp_train_range under GNN_MLP_GRAPH=1 (the library captures one pass on
+    its own stream) and data_parallel.GraphedSteps (stream capture on a torch side stream, the route
+    bench.py's N-GPU runs take) -- against the same steps enqueued eagerly: same kernels in the same
+    order, so weights and momentum must be BITWISE equal; then fp64 numpy spot rows of the result."""
+    import torch
+    from gnn_amd import data_parallel as dp
+    from tests import np_oracle
+    dims, B, nb = [784, 1024, 1024, 1024, 10], 256, 3
+    X, Y = make_batch(dims, B * nb, seed=55, sparse=True)
+    firsts = [b * B for b in range(nb)]
+    passes = 3
+
+    def fresh():
+        n = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+        n.set_weights(n.get_weights() * 0.05)     # as test_full_size_configs_properties: keep the softmax unsaturated
+        n.upload_dataset(X, Y)
+        return n
+    eager = fresh()
+    w_init = eager.get_weights()
+    for _ in range(passes):
+        for f in firsts:
+            eager.gradient_step_range(f, B, 0.0125, 0.9)
+    monkeypatch.setenv("GNN_MLP_GRAPH", "1")
+    lib_graph = fresh()                            # env is read at create
+    monkeypatch.delenv("GNN_MLP_GRAPH")
+    lib_graph.train_range(0, B, passes * nb, 0.0125, 0.9)
+    assert lib_graph.time == eager.time == passes * nb
+    assert np.array_equal(lib_graph.get_weights(), eager.get_weights())
+    assert np.array_equal(lib_graph.get_momentum(), eager.get_momentum())
+    # the split path (gradient buffer + flat update) eagerly and under GraphedSteps
+    split_eager, split_graph = fresh(), fresh()
+    st_e = dp.DataParallelStep(dp.HipEngine(split_eager, torch))
+    for _ in range(passes):
+        for f in firsts:
+            st_e.step(f, B, 0.0125, 0.9)
+    side = torch.cuda.Stream()
+    st_g = dp.DataParallelStep(dp.HipEngine(split_graph, torch, stream=side))
+    g = dp.GraphedSteps(st_g, torch, side, firsts, B, 0.0125, 0.9)   # one eager pass, then the capture
+    for _ in range(passes - 1):
+        g.replay()
+    torch.cuda.synchronize()
+    assert split_graph.time == split_eager.time == passes * nb
+    assert np.array_equal(split_graph.get_weights(), split_eager.get_weights())
+    assert np.abs(split_graph.get_weights() - eager.get_weights()).max() <= 1e-6   # fused update vs split update
+    # oracle spot check of what the captured steps computed: first step, 8 rows' worth of gradient
+    Ws = np_oracle.split(w_init, dims)
+    one = fresh()
+    gref = np_oracle.gradient(Ws, X[:8], Y[:8], 0)
+    g8 = one.calculateWeightGradient(X[:8], Y[:8])
+    g8f = np.concatenate([g8[l].ravel() for l in sorted(g8)])
+    assert np.abs(g8f - gref).max() <= 5e-5 * np.abs(gref).max()
+
+
 def test_argmax_nan_rule(gnn, oracle_mod):
     """MT:166-168 with NaNs: the scan starts at actual = 0 and `x >= NaN` is false, so a NaN at
     index 0 is sticky.  A NaN weight makes every softmax probability NaN -> label 0."""

@@ -85,6 +85,19 @@ def test_checkpoint_round_trip(gnn, tmp_path):
     c = gnn.SoftmaxCrossEntropyNeuralNet([784, 100, 40, 10], max_batch=B)
     with pytest.raises(gnn.GnnError):
         c.load_checkpoint(tmp_path / "ck.bin")
+    # same dims, another net: the header carries output kind, activations, loss and dtype
+    for other in (gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=gnn.ACT_SIGMOID, max_batch=B),
+                  gnn.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn.DTYPE_BF16, max_batch=B),
+                  gnn.GeneralNeuralNet(dims, max_batch=B)):
+        with pytest.raises(gnn.GnnError, match="configuration differs"):
+            other.load_checkpoint(tmp_path / "ck.bin")
+    # truncation, trailing bytes and a flipped payload byte are caught by length + checksum
+    raw = (tmp_path / "ck.bin").read_bytes()
+    flipped = bytearray(raw); flipped[len(raw) // 2] ^= 1
+    for name, data in (("short", raw[:-9]), ("long", raw + b"x"), ("flip", bytes(flipped))):
+        (tmp_path / name).write_bytes(data)
+        with pytest.raises(gnn.GnnError, match="checksum"):
+            gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B).load_checkpoint(tmp_path / name)
 
 
 def test_train_sampled_ragged_batches_and_chunks(gnn, oracle_mod):
