@@ -19,10 +19,15 @@ line and returns the worst exit code.
 
 Graph or eager (data-parallel path) is decided BEFORE anything runs: `--dp-mode graph` captures
 one pass over the resident batches -- kernels and the RCCL all-reduce -- into one HIP graph.  If
-that capture does not produce a graph, the stream it ran on is left invalidated and the process
-must not issue further GPU work (round 1: later HIP calls crashed): every rank exits with
-EXIT_CAPTURE_FAILED at once and the eager run happens in FRESH processes (the launcher starts a
-new group; a rank started by torch.distributed.run starts its own fresh child).
+that capture does not produce a graph, the stream it ran on stays invalidated, and a process that
+holds an RCCL process group then dies within ~100 ms: torch's ProcessGroupNCCL watchdog thread
+polls the end event of the collective it enqueued on that stream (hipEventQuery ->
+c10_hip_check -> uncaught c10::Error -> abort; this is the round-1 "later HIP calls crashed").
+So a rank whose capture failed reports it through a CPU-side store and leaves AT ONCE with
+EXIT_CAPTURE_FAILED, its peers follow, and the eager run happens in FRESH processes: a process that
+never touches the GPU supervises the attempt(s) -- the launcher for a group it started itself, a
+per-rank supervisor when the ranks were started by torch.distributed.run.  In `auto` mode any
+failure of the graph attempt (not only a reported capture failure) is followed by one eager attempt.
 """
 import argparse
 import datetime
@@ -157,9 +162,10 @@ def launch(args, argv):
                 return 1
             print(lines[0], flush=True)
             return 0
-        if rc != EXIT_CAPTURE_FAILED or i + 1 == len(modes):
+        if i + 1 == len(modes):
             break
-        print("bench.py launcher: hipGraph capture failed in the ranks; starting fresh ranks in eager mode", file=sys.stderr)
+        print("bench.py launcher: the hipGraph attempt failed in the ranks (%s); starting fresh ranks in eager mode"
+              % ("capture failed" if rc == EXIT_CAPTURE_FAILED else "exit code %d" % rc), file=sys.stderr)
     print("bench.py launcher: ranks failed (exit code %d)" % rc, file=sys.stderr)
     return rc
 
@@ -211,13 +217,31 @@ def cpu_baseline(seconds=12.0):
                       "SCE:297-346; C restatement, not a JVM run)" % (steps, BATCH)}
 
 
-def fresh_eager_child(argv):
-    """A rank started by torch.distributed.run whose capture failed: the eager run goes to a fresh
-    child process (same rank, next rendezvous port); this process only waits and relays."""
-    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29511")) + 1), GNN_BENCH_LAUNCHER="1")
-    cmd = [sys.executable, os.path.abspath(__file__)] + child_argv(argv, "eager")
-    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
-    return p.returncode, p.stdout
+def supervise_own_rank(args, argv):
+    """This process was started as ONE rank by someone else (torch.distributed.run), or is the single
+    process of `--dp-path`.  It stays off the GPU and runs the rank as a child: the graph attempt
+    first, and if that fails a fresh child in eager mode on the next rendezvous port (every rank's
+    supervisor takes the same decision from the same exit code)."""
+    modes = [args.dp_mode] if args.dp_mode != "auto" else ["graph", "eager"]
+    rc = 1
+    for i, mode in enumerate(modes):
+        env = dict(os.environ, GNN_BENCH_LAUNCHER="1")
+        if i > 0:
+            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 1)
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)   # rank 0 of the fresh group hosts the new store itself
+        cmd = [sys.executable, os.path.abspath(__file__)] + child_argv(argv, mode)
+        if args.inject_capture_failure and mode == "graph":
+            cmd.append("--inject-capture-failure")
+        p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
+        rc = p.returncode
+        if rc == 0:
+            if p.stdout.strip():
+                print(p.stdout.strip(), flush=True)
+            return 0
+        if i + 1 < len(modes):
+            print("bench.py rank supervisor: the hipGraph attempt failed (%s); fresh child in eager mode"
+                  % ("capture failed" if rc == EXIT_CAPTURE_FAILED else "exit code %d" % rc), file=sys.stderr)
+    return rc if rc > 0 else 128 - rc
 
 
 def worker(args, argv):
@@ -291,6 +315,10 @@ def worker(args, argv):
             # through a CPU-side store (no GPU call after a failed capture), then either all go on or
             # all leave.
             ok = True
+            store = None
+            if world > 1:   # made BEFORE the attempt: after a failure there is no time to set one up
+                store = dist.TCPStore("127.0.0.1", int(os.environ["MASTER_PORT"]) + 3, world, rank == 0,
+                                      timeout=datetime.timedelta(seconds=120))
             try:
                 graphed = dp.GraphedSteps(stepper, torch, side, [b * BATCH for b in range(N_BATCHES)],
                                           BATCH, STEP, MOMENTUM, inject_failure=args.inject_capture_failure)
@@ -298,26 +326,24 @@ def worker(args, argv):
                 ok = False
                 print("rank %d: hipGraph capture failed (%s: %s)" % (rank, type(e).__name__,
                                                                      (str(e).splitlines() or [""])[0]), file=sys.stderr)
-            all_ok = ok
-            if world > 1:
-                store = dist.TCPStore("127.0.0.1", int(os.environ["MASTER_PORT"]) + 3, world, rank == 0,
-                                      timeout=datetime.timedelta(seconds=120))
-                store.set("cap%d" % rank, "1" if ok else "0")
-                all_ok = all(store.get("cap%d" % r) == b"1" for r in range(world))
-                store.set("seen%d" % rank, "1")
-                if rank == 0:   # the store's server stays up until every rank has read the verdict
-                    for r in range(world):
-                        store.get("seen%d" % r)
-            if not all_ok:
-                # No further GPU work in this process, and no teardown that could touch the
-                # invalidated stream or wait for peers: leave at once.
-                sys.stderr.flush()
-                if os.environ.get("GNN_BENCH_LAUNCHER") == "1":
-                    os._exit(EXIT_CAPTURE_FAILED)      # our launcher starts fresh ranks in eager mode
-                rc, out = fresh_eager_child(argv)      # started by torch.distributed.run: own fresh child
-                if rank == 0 and rc == 0:
-                    emit(out.strip())
-                os._exit(rc)
+            if not ok:
+                # The stream is invalidated and the RCCL watchdog is about to find out: tell the peers and
+                # leave at once -- no further GPU call, no teardown, no waiting.
+                try:
+                    if store is not None:
+                        store.set("cap%d" % rank, "0")
+                finally:
+                    sys.stderr.flush()
+                    os._exit(EXIT_CAPTURE_FAILED)
+            if store is not None:
+                store.set("cap%d" % rank, "1")
+                try:
+                    peers_ok = all(store.get("cap%d" % r) == b"1" for r in range(world))
+                except Exception:   # the store's host (rank 0) has already left
+                    peers_ok = False
+                if not peers_ok:
+                    sys.stderr.flush()
+                    os._exit(EXIT_CAPTURE_FAILED)
 
         def run(first_batch, n, eager=False):
             s = 0
@@ -478,6 +504,10 @@ def main():
         sys.exit(launch(args, argv))       # nothing GPU-related has been imported in this process
     if world_env is not None and int(world_env) != args.gpus:
         args.gpus = int(world_env)
+    is_dp = args.gpus > 1 or args.dp_path
+    first_mode = args.dp_mode if args.dp_mode != "auto" else ("graph" if args.backend == "nccl" or args.inject_capture_failure else "eager")
+    if is_dp and first_mode == "graph" and os.environ.get("GNN_BENCH_LAUNCHER") != "1":
+        sys.exit(supervise_own_rank(args, argv))   # a graph attempt is never made in an unsupervised process
     worker(args, argv)
 
 

@@ -89,7 +89,9 @@ def test_bench_line_data_parallel_path():
 
 def test_bench_capture_failure_under_external_launcher():
     """Started the way torch.distributed.run starts a rank (WORLD_SIZE in the environment, no launcher of
-    ours): a failed capture hands the eager run to the rank's own fresh child process."""
+    ours): the rank supervises itself -- the process that was started stays off the GPU, the graph attempt
+    runs in a child (with RCCL: the case in which the capturing process is killed by torch's NCCL watchdog
+    ~100 ms after the failed capture), and the eager run in a second, fresh child."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     env.pop("GNN_BENCH_LAUNCHER", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "128", "--warmup", "64",
@@ -100,4 +102,5 @@ def test_bench_capture_failure_under_external_launcher():
     assert len(lines) == 1
     line = json.loads(lines[0])
     check(line)
-    assert "hipGraph capture failed" in out.stderr and line["config"]["dp_mode"] == "eager"
+    assert "hipGraph capture failed" in out.stderr and "rank supervisor" in out.stderr
+    assert line["config"]["dp_mode"] == "eager"
