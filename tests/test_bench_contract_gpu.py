@@ -26,7 +26,7 @@ def run_bench(*flags, want_stderr=False):
     return (json.loads(lines[0]), out.stderr) if want_stderr else json.loads(lines[0])
 
 
-def check(line, n_gpus=1, dtype="f32"):
+def check(line, n_gpus=1, dtype="f32", shared_gpu=False):
     for k in KEYS:
         assert k in line, k
     assert line["metric"].startswith("training samples/sec") and line["unit"] == "samples/s"
@@ -38,7 +38,8 @@ def check(line, n_gpus=1, dtype="f32"):
     r = line["roofline"]
     for k in ["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "share_of_step", "other"]:
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["peak"] > 0
+    # (ranks time-slicing ONE GPU stretch a kernel's begin-to-end time to milliseconds: frac rounds to 0 there)
+    assert r["bound"] in ("hbm", "mfma") and (0 if shared_gpu else 1e-4) <= r["frac"] < 1 and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # the roofline kernel is the one with the largest share of the step
     assert all(r["avg_launch_us"] >= o["avg_us"] for o in r["other"].values())
@@ -63,7 +64,7 @@ def test_bench_two_ranks_self_launched():
     """The driver's call shape at N > 1: `bench.py --gpus N` with no WORLD_SIZE.  bench.py starts the
     ranks itself (here both on the one GPU, gloo carrying the all-reduce: numbers meaningless)."""
     line = run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu")
-    check(line, n_gpus=2)
+    check(line, n_gpus=2, shared_gpu=True)
     c = line["config"]
     assert c["backend"] == "gloo" and c["world_size"] == 2 and c["dp_mode"] == "eager"
     assert c["dp_replicas_identical"] is True and c["parallelism"] == "dp2"
@@ -74,7 +75,7 @@ def test_bench_capture_failure_hands_over_to_fresh_eager_ranks():
     call that is not permitted while capturing) leaves the capturing stream invalidated; the ranks
     must stop using the GPU and exit, and the eager run must come from FRESH processes."""
     line, err = run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--inject-capture-failure", want_stderr=True)
-    check(line, n_gpus=2)
+    check(line, n_gpus=2, shared_gpu=True)
     assert "hipGraph capture failed" in err and "starting fresh ranks in eager mode" in err
     assert line["config"]["dp_mode"] == "eager" and line["config"]["dp_replicas_identical"] is True
 

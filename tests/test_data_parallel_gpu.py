@@ -59,8 +59,8 @@ def _worker(rank, world, port, out_dir, bf16):
         assert stepper.world == world
         for s in range(STEPS):
             stepper.step(s * B_LOCAL, B_LOCAL, 0.0125, 0.9)
-            if s == 5:
-                np.save(os.path.join(out_dir, "w%d_s6.npy" % rank), net.get_weights())
+            if s == 2:
+                np.save(os.path.join(out_dir, "w%d_s3.npy" % rank), net.get_weights())
         torch.cuda.synchronize()
         assert net.time == STEPS
         assert stepper.replicas_in_lockstep(torch)
@@ -90,12 +90,14 @@ def test_two_ranks_one_gpu_equal_single_process(gnn, tmp_path, bf16):
     assert np.abs(w0 - ref.get_weights()).max() <= (1e-4 if bf16 else 4e-6)
     if bf16:
         # and the bf16-aware fp64 oracle on the GLOBAL batch (tests/np_oracle.py: every GEMM operand
-        # rounded to bf16, f32-exact inputs) -- the tolerance of tests/test_bf16_gpu.py per step count
+        # rounded to bf16, f32-exact inputs)
         from tests import np_oracle
         ini = gnn.SoftmaxCrossEntropyNeuralNet(DIMS, max_batch=16)
         w, v = ini.get_weights(), np.zeros(ini.n_params)
         X32 = X.astype(np.float32).astype(np.float64)
-        n_or = 6
+        n_or = 3
         for s in range(n_or):
             w, v = np_oracle.gradient_step_bf16(w, v, DIMS, X32[s * Bg:(s + 1) * Bg], Y[s * Bg:(s + 1) * Bg], 0.0125, 0.9, 0)
-        assert np.abs(np.load(tmp_path / "w0_s6.npy") - w).max() <= 4e-4   # the data-parallel replicas themselves
+        # the data-parallel replicas themselves after 3 global steps (tests/test_bf16_gpu.py allows one GPU 2e-4
+        # after 3 steps; the two partial sums add their own reordering)
+        assert np.abs(np.load(tmp_path / "w0_s3.npy") - w).max() <= 3e-4
