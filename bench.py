@@ -353,7 +353,7 @@ def worker(args, argv):
                     graphed.replay()
                     s += N_BATCHES
                 else:
-                    stepper.step(b * BATCH, BATCH, STEP, MOMENTUM)
+                    stepper.step(b * BATCH, BATCH, STEP, MOMENTUM, next_first=((b + 1) % N_BATCHES) * BATCH)
                     s += 1
 
     run(0, W)

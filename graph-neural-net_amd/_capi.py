@@ -59,11 +59,13 @@ SYMBOLS = [
     ("gnn_mlp_compute_gradient_range", C.c_int, [_H, C.c_int64, C.c_int]),
     ("gnn_mlp_compute_gradient", C.c_int, [_H, _dp, _dp, C.c_int]),
     ("gnn_mlp_apply_update", C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
+    ("gnn_mlp_hint_next_range", C.c_int, [_H, C.c_int64, C.c_int]),
     ("gnn_mlp_synchronize", C.c_int, [_H]),
     ("gnn_mlp_advance_time", C.c_int, [_H, C.c_int]),
     ("gnn_mlp_recover_stream", C.c_int, [_H]),
     ("gnn_mlp_specialize", C.c_int, [_H]),
     ("gnn_mlp_specialization", C.c_int, [_H]),
+    ("gnn_mlp_step_launches", C.c_int, [_H]),
     ("gnn_mlp_timing_enable", C.c_int, [_H, C.c_int]),
     ("gnn_mlp_timing_read", C.c_int, [_H, C.c_int, _dp, C.POINTER(C.c_int64)]),
 ]

@@ -295,10 +295,10 @@ __global__ __launch_bounds__(NTHR) void grad_update_kernel(GradParams p) {
         }
         if (FUSED) { // ((step*G)/B) + (momentum*prev), SCE:333
             float4 adj, wn_;
-            adj.x = p.step_over_b * gsum.x + p.momentum * v_old.x;
-            adj.y = p.step_over_b * gsum.y + p.momentum * v_old.y;
-            adj.z = p.step_over_b * gsum.z + p.momentum * v_old.z;
-            adj.w = p.step_over_b * gsum.w + p.momentum * v_old.w;
+            adj.x = sgd_adj(p.step_over_b, gsum.x, p.momentum, v_old.x);
+            adj.y = sgd_adj(p.step_over_b, gsum.y, p.momentum, v_old.y);
+            adj.z = sgd_adj(p.step_over_b, gsum.z, p.momentum, v_old.z);
+            adj.w = sgd_adj(p.step_over_b, gsum.w, p.momentum, v_old.w);
             wn_.x = w_old.x - adj.x; wn_.y = w_old.y - adj.y; wn_.z = w_old.z - adj.z; wn_.w = w_old.w - adj.w;
             *reinterpret_cast<float4 *>(L.W + e_off) = wn_;
             *reinterpret_cast<float4 *>(L.V + e_off) = adj;
@@ -417,10 +417,10 @@ __global__ __launch_bounds__(512) void grad_update64_kernel(GradParams p) {
         const float4 gsum = make_float4(g0.x + g1.x, g0.y + g1.y, g0.z + g1.z, g0.w + g1.w);
         if (FUSED) { // ((step*G)/B) + (momentum*prev), SCE:333
             float4 adj, wn_;
-            adj.x = p.step_over_b * gsum.x + p.momentum * v_old[i].x;
-            adj.y = p.step_over_b * gsum.y + p.momentum * v_old[i].y;
-            adj.z = p.step_over_b * gsum.z + p.momentum * v_old[i].z;
-            adj.w = p.step_over_b * gsum.w + p.momentum * v_old[i].w;
+            adj.x = sgd_adj(p.step_over_b, gsum.x, p.momentum, v_old[i].x);
+            adj.y = sgd_adj(p.step_over_b, gsum.y, p.momentum, v_old[i].y);
+            adj.z = sgd_adj(p.step_over_b, gsum.z, p.momentum, v_old[i].z);
+            adj.w = sgd_adj(p.step_over_b, gsum.w, p.momentum, v_old[i].w);
             wn_.x = w_old[i].x - adj.x; wn_.y = w_old[i].y - adj.y; wn_.z = w_old[i].z - adj.z; wn_.w = w_old[i].w - adj.w;
             *reinterpret_cast<float4 *>(L.W + e_off[i]) = wn_;
             *reinterpret_cast<float4 *>(L.V + e_off[i]) = adj;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
                         p.C[off] = live ? v * act_prime_from_a(p.act, a) : 0.f;
                     } else { // EPI_SGD on the f32 masters: ((step*G)/B) + (momentum*prev), SCE:333
                         if (live) {
-                            const float adj = p.step_over_b * v + p.momentum * p.V[off];
+                            const float adj = sgd_adj(p.step_over_b, v, p.momentum, p.V[off]);
                             p.W[off] -= adj;
                             p.V[off] = adj;
                         }

@@ -8,6 +8,7 @@
 #include "fused_kernels.h"
 #include "gemm_bf16.h"
 #include "middle4_kernel.h"
+#include "tile_step_kernel.h"
 #include "kernels.h"
 
 #include <hip/hip_ext.h>
@@ -81,8 +82,20 @@ struct gnn_mlp {
     bool mid4 = false;        // middle4_kernel: every middle weight matrix resident in LDS
     Mid4Params mid4p{};
     size_t mid4_lds_bytes = 0;
-    const void *mid4_fn[2] = {nullptr, nullptr}; // [backward]
-    hipFunction_t mid4_jit[2] = {nullptr, nullptr}; // run-time instantiation (jit.h), preferred when set
+    const void *mid4_fn[3] = {nullptr, nullptr, nullptr}; // forward only / forward + backward / the same with A_1 from K slabs
+    hipFunction_t mid4_jit[3] = {nullptr, nullptr, nullptr}; // run-time instantiation (jit.h), preferred when set
+
+    // two-launch step (tile_step_kernel.h): the tile kernel of step s also makes the first-layer K slabs of step s+1
+    bool chain = false;
+    TileStepParams tsp{};
+    int ts_tiles = 0, ts_tiles0 = 0; // blocks of all layers / of layer 0 alone
+    float *slabs = nullptr;
+    int n_slabs = 0;
+    // the batch whose first-layer sums (for the CURRENT weights) the slabs hold
+    bool slab_valid = false; const float *slab_a0 = nullptr; const int32_t *slab_idx = nullptr; int slab_B = 0;
+    // the batch the next gradient computation will run on (gnn_mlp_hint_next_range, train loops); consumed by the
+    // next kernel that updates the weights
+    bool have_next = false; const float *next_a0 = nullptr; const int32_t *next_idx = nullptr; int next_B = 0;
     int specialization = 0;   // 0 runtime-shape kernels, 1 prebuilt static shape, 2 run-time instantiation
     bool jit_tried = false;
     int steps_seen = 0;       // gradient computations so far: the 16th triggers the specialisation
@@ -97,7 +110,7 @@ struct gnn_mlp {
     const int32_t *cur_idx = nullptr; // device row indices of the batch being stepped (fused path reads rows through them)
 
     bool timing = false;
-    TimerClass timers[4];
+    TimerClass timers[5];
 
     // development / test switches, read ONCE at create (never on the step path)
     int env_path = 0;          // GNN_MLP_PATH: 0 default, 1 "generic", 2 "nomid4"
@@ -106,6 +119,7 @@ struct gnn_mlp {
     bool env_graph = false;    // GNN_MLP_GRAPH=1: train_range replays a captured pass
     bool env_jit_off = false;  // GNN_MLP_JIT=0
     bool env_static_off = false; // GNN_MLP_STATIC=0
+    bool env_chain_off = false;  // GNN_MLP_CHAIN=0: three launches per step (fwd_first / middle4 / grad_update)
 };
 
 namespace {
@@ -119,6 +133,7 @@ void read_env(gnn_mlp *h) {
     h->env_graph = is("GNN_MLP_GRAPH", "1");
     h->env_jit_off = is("GNN_MLP_JIT", "0");
     h->env_static_off = is("GNN_MLP_STATIC", "0");
+    h->env_chain_off = is("GNN_MLP_CHAIN", "0");
 }
 
 // every launch since the last check was accepted: the runtime's sticky error and the return codes of
@@ -318,6 +333,7 @@ void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_
 // ---- fused small-net path ---------------------------------------------------------------------
 
 void plan_mid4(gnn_mlp *h);
+void plan_chain(gnn_mlp *h);
 
 // Decides whether the net fits the fused path and lays out the middle kernel's LDS.
 void plan_fused(gnn_mlp *h) {
@@ -358,7 +374,7 @@ void plan_fused(gnn_mlp *h) {
     }
     // preferred: 4-row blocks with LDS-resident middle weights
     plan_mid4(h);
-    if (h->mid4) { h->fused = true; return; }
+    if (h->mid4) { h->fused = true; plan_chain(h); return; }
     // the middle weights do not fit LDS: per-layer tiled GEMMs for the middle, still bracketed by
     // the one-launch first layer and the one-launch gradient+update (a 16-row kernel that streamed
     // the middle weights from L2 was 15-40 % slower than this on every such shape and was removed)
@@ -368,9 +384,11 @@ void plan_fused(gnn_mlp *h) {
 
 // ---- middle4_kernel plan ----------------------------------------------------------------------
 // kernel table: [shape policy][activation][output kind][backward]
-template <class SH, int OUTK> const void *mid4_fn_sh(int act, bool bwd) {
-#define GNN_M4(A) (bwd ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true>) \
-                       : reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, false>))
+// variant: 0 forward only, 1 forward + backward, 2 forward + backward with A_1 from the K slabs of tile_step_kernel
+template <class SH, int OUTK> const void *mid4_fn_sh(int act, int variant) {
+#define GNN_M4(A) (variant == 2 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true, false, true>)  \
+                   : variant == 1 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true>)             \
+                                  : reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, false>))
     switch (act) {
     case 0: return GNN_M4(0);
     case 1: return GNN_M4(1);
@@ -391,18 +409,17 @@ template <class SH> bool shape_matches(const gnn_mlp *h) {
     return true;
 }
 
-const void *mid4_function(const gnn_mlp *h, bool bwd) {
+const void *mid4_function(const gnn_mlp *h, int variant) {
     const bool allow_static = !h->env_static_off;
     if (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE) {
-        if (shape_matches<ShapeMnistA>(h)) return mid4_fn_sh<ShapeMnistA, 0>(h->inner_act, bwd);
-        if (shape_matches<ShapeMnistB>(h)) return mid4_fn_sh<ShapeMnistB, 0>(h->inner_act, bwd);
+        if (shape_matches<ShapeMnistA>(h)) return mid4_fn_sh<ShapeMnistA, 0>(h->inner_act, variant);
+        if (shape_matches<ShapeMnistB>(h)) return mid4_fn_sh<ShapeMnistB, 0>(h->inner_act, variant);
     }
     // runtime extents: layer count templated (3..6, else generic), activation read from the arguments
-#define GNN_M4R(NL) (h->out_kind == GNN_OUT_SOFTMAX_CE                                                                    \
-        ? (bwd ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, 0, true>)                              \
-               : reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, 0, false>))                            \
-        : (bwd ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, 1, true>)                              \
-               : reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, 1, false>)))
+#define GNN_M4RO(NL, OK) (variant == 2 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true, false, true>) \
+                          : variant == 1 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true>)           \
+                                         : reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, false>))
+#define GNN_M4R(NL) (h->out_kind == GNN_OUT_SOFTMAX_CE ? GNN_M4RO(NL, 0) : GNN_M4RO(NL, 1))
     switch (h->L) {
     case 3: return GNN_M4R(3);
     case 4: return GNN_M4R(4);
@@ -411,6 +428,7 @@ const void *mid4_function(const gnn_mlp *h, bool bwd) {
     default: return GNN_M4R(0);
     }
 #undef GNN_M4R
+#undef GNN_M4RO
 }
 
 void plan_mid4(gnn_mlp *h) {
@@ -431,8 +449,8 @@ void plan_mid4(gnn_mlp *h) {
         h->specialization = (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE &&
                              (shape_matches<ShapeMnistA>(h) || shape_matches<ShapeMnistB>(h))) ? 1 : 0;
     }
-    for (int bwd = 0; bwd < 2; bwd++) {
-        h->mid4_fn[bwd] = mid4_function(h, bwd != 0);
+    for (int bwd = 0; bwd < 3; bwd++) {
+        h->mid4_fn[bwd] = mid4_function(h, bwd);
         if (hipFuncSetAttribute(h->mid4_fn[bwd], hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)h->mid4_lds_bytes) != hipSuccess) {
             (void)hipGetLastError();
@@ -442,16 +460,49 @@ void plan_mid4(gnn_mlp *h) {
     h->mid4 = true;
 }
 
+// ---- two-launch step: tile_step_kernel plan ----------------------------------------------------
+// Every layer's weight matrix in 64 x 16 tiles, one grid; layer 0's tiles first (they also make the next
+// batch's first-layer K slabs).  Needs the row-block kernel (middle4) and at most MID4_MAX_SLABS slabs.
+void plan_chain(gnn_mlp *h) {
+    h->chain = false;
+    if (h->env_chain_off || !h->mid4 || h->dtype != GNN_DTYPE_F32) return;
+    const int L = h->L;
+    h->n_slabs = (h->ld[0] + TS_TM - 1) / TS_TM;
+    if (h->n_slabs > MID4_MAX_SLABS) return;
+    TileStepParams &t = h->tsp;
+    t = TileStepParams{};
+    t.n_layers = L - 1;
+    int tiles = 0;
+    for (int l = 0; l < L - 1; l++) {
+        GradLayer &gl = t.layer[l];
+        gl.A = h->act[l]; gl.lda = h->ld[l];
+        gl.D = h->delta[l + 1]; gl.ldd = h->ld[l + 1];
+        gl.W = h->W + h->w_off[l]; gl.V = h->V + h->w_off[l]; gl.G = h->G + h->w_off[l];
+        gl.M = h->ld[l]; gl.N = h->ld[l + 1];
+        gl.tiling = make_xcd_tiling((gl.M + TS_TM - 1) / TS_TM, gl.N / TS_TN);
+        gl.block_begin = tiles;
+        tiles += gl.tiling.blocks();
+        if (l == 0) h->ts_tiles0 = tiles;
+    }
+    h->ts_tiles = tiles;
+    const size_t n = (size_t)h->n_slabs * h->cap_rows * h->ld[1];
+    if (hipMalloc(reinterpret_cast<void **>(&h->slabs), sizeof(float) * n) != hipSuccess) { (void)hipGetLastError(); h->slabs = nullptr; return; }
+    if (hipMemsetAsync(h->slabs, 0, sizeof(float) * n, h->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    t.slabs = h->slabs; t.slab_rows = h->cap_rows; t.ldz = h->ld[1];
+    h->chain = true;
+}
+
 // Run-time instantiation of middle4_kernel for this net's shape (jit.h); silent no-op when the
 // net is already specialised, does not take the middle4 path, or hiprtc is unavailable.
 void try_specialize(gnn_mlp *h) {
     if (!h->mid4 || h->specialization != 0 || h->jit_tried) return;
     h->jit_tried = true;
     if (h->env_jit_off) return;
-    const jit::Specialised *sp = jit::get_middle4(h->device, h->dims.data(), h->L, h->inner_act, h->out_kind, h->mid4_lds_bytes);
+    const jit::Specialised *sp = jit::get_middle4(h->device, h->dims.data(), h->L, h->inner_act, h->out_kind, h->chain, h->mid4_lds_bytes);
     if (!sp) return;
     h->mid4_jit[0] = sp->fn[0];
     h->mid4_jit[1] = sp->fn[1];
+    h->mid4_jit[2] = sp->fn[2];
     h->specialization = 2;
 }
 
@@ -495,11 +546,13 @@ void launch_fwd_first(gnn_mlp *h, const float *a0, int B) {
 }
 
 // forward of the middle4 path; backward = also delta_1..delta_{L-1}
+// from_slabs: A_1 = f(sum of the K slabs) (tile_step_kernel made them); else fwd_first_kernel writes act[1] first
 void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
-                   bool want_loss, bool want_label) {
-    launch_fwd_first(h, a0, B);
+                   bool want_loss, bool want_label, bool from_slabs = false) {
+    if (!from_slabs) launch_fwd_first(h, a0, B);
     {
         Mid4Params m4 = h->mid4p;
+        m4.slabs = h->slabs; m4.slab_rows = h->cap_rows; m4.n_slabs = h->n_slabs;
         m4.Y = y; m4.ldy = h->ld[h->L - 1];
         m4.prob = want_prob ? h->prob : nullptr;
         m4.loss = want_loss ? h->lossv : nullptr;
@@ -508,7 +561,7 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
         m4.row_idx = h->cur_idx;
         void *args[] = {&m4};
         // every padded row is processed: rows >= B become zeros
-        const int bw = backward ? 1 : 0;
+        const int bw = from_slabs ? 2 : backward ? 1 : 0;
         const unsigned grid = (unsigned)(pad_up(B) / 4);
         TimerClass &tc = h->timers[GNN_K_MIDDLE];
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -549,6 +602,63 @@ void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float
     } else {
         if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<true>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);
         else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<false>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);
+    }
+}
+
+// ---- tile_step_kernel launches ------------------------------------------------------------------
+struct NextBatch { const float *a0; const int32_t *idx; int B; };
+
+// gsrc / gdst / fwd as in tile_step_kernel.h; fwd_only_layer0: the grid covers layer 0's tiles only
+void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, const float *a0, int B, float step_over_b, float momentum) {
+    TileStepParams t = h->tsp;
+    t.layer[0].A = a0;
+    for (int l = 0; l < t.n_layers; l++) t.layer[l].G = h->G + h->w_off[l];
+    t.K = pad_up(B); t.k_true = B;
+    t.row_idx = h->cur_idx;
+    t.step_over_b = step_over_b; t.momentum = momentum;
+    const bool fwd = next != nullptr;
+    if (fwd) { t.An = next->a0; t.ldan = h->ld[0]; t.next_idx = next->idx; t.next_rows = next->B; t.next_K = pad_up(next->B); }
+    const bool fwd_only = gsrc == 0;
+    const dim3 grid(fwd_only ? h->ts_tiles0 : h->ts_tiles), block(TS_THREADS);
+    if (fwd_only) t.n_layers = 1;
+    const int cls = fwd_only ? GNN_K_FWD_GEMM0 : GNN_K_GRAD_GEMM0;
+    if (fwd_only) launch_timed(h, cls, tile_step_kernel<0, 0, true>, grid, block, 0, t);
+    else if (gsrc == 1 && gdst == 1) launch_timed(h, cls, tile_step_kernel<1, 1, false>, grid, block, 0, t);
+    else if (gsrc == 1 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_kernel<1, 2, false>, grid, block, 0, t);
+    else if (gsrc == 1 && gdst == 2 && fwd) launch_timed(h, cls, tile_step_kernel<1, 2, true>, grid, block, 0, t);
+    else if (gsrc == 2 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_kernel<2, 2, false>, grid, block, 0, t);
+    else launch_timed(h, cls, tile_step_kernel<2, 2, true>, grid, block, 0, t);
+}
+
+bool slabs_hold(const gnn_mlp *h, const float *a0, const int32_t *idx, int B) {
+    return h->slab_valid && h->slab_a0 == a0 && h->slab_idx == idx && h->slab_B == B;
+}
+// the hint is good for ONE weight update
+bool take_next(gnn_mlp *h, NextBatch *nb) {
+    if (!h->have_next) return false;
+    h->have_next = false;
+    *nb = NextBatch{h->next_a0, h->next_idx, h->next_B};
+    return true;
+}
+void slabs_now_hold(gnn_mlp *h, const NextBatch &nb) { h->slab_valid = true; h->slab_a0 = nb.a0; h->slab_idx = nb.idx; h->slab_B = nb.B; }
+
+// One gradient computation on the two-launch path.  `resident`: the rows live in the dataset (a staging
+// buffer holds other data under the same address at the next call, so its slabs are never reused).
+void chain_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum, bool resident) {
+    if (!slabs_hold(h, a0, h->cur_idx, B)) {
+        const NextBatch self{a0, h->cur_idx, B};
+        launch_tile_step(h, 0, 0, &self, a0, B, 0.f, 0.f); // chain start: the slabs of this batch from the weights as they are
+    }
+    h->slab_valid = false;
+    fused_forward(h, a0, y, B, true, false, false, false, true);
+    NextBatch nb{};
+    if (fused_update) {
+        const bool fwd = take_next(h, &nb);
+        launch_tile_step(h, 1, 2, fwd ? &nb : nullptr, a0, B, step_over_b, momentum);
+        if (fwd) slabs_now_hold(h, nb);
+    } else {
+        launch_tile_step(h, 1, 1, nullptr, a0, B, 0.f, 0.f);
+        if (resident) slabs_now_hold(h, NextBatch{a0, h->cur_idx, B}); // weights unchanged: the slabs still describe this batch
     }
 }
 
@@ -607,7 +717,10 @@ void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_pr
     if (tail) launch_tail(h, a0, y, B, false, want_prob, want_loss, want_label);
     else run_output(h, y, B, want_prob, false, want_loss, want_label);
 }
-void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum) {
+void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum,
+                 bool resident = false) {
+    if (h->chain) { chain_gradient(h, a0, y, B, fused_update, step_over_b, momentum, resident); return; }
+    h->have_next = false;
     if (h->mid4) {
         fused_forward(h, a0, y, B, true, false, false, false);
         fused_gradient(h, a0, B, fused_update, step_over_b, momentum);
@@ -671,10 +784,10 @@ void maybe_specialize(gnn_mlp *h) {
     try_specialize(h);
 }
 
-int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step, double momentum) {
+int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step, double momentum, bool resident) {
     maybe_specialize(h);
     ScopedTimer tm(h, GNN_K_STEP);
-    do_gradient(h, a0, y, B, true, (float)(step / (double)B), (float)momentum);
+    do_gradient(h, a0, y, B, true, (float)(step / (double)B), (float)momentum, resident);
     h->time++;
     TRY_LAUNCHES(h);
     return GNN_OK;
@@ -711,6 +824,7 @@ int get_flat(gnn_mlp *h, const float *dev, double *flat) {
 }
 int set_flat(gnn_mlp *h, float *dev, const double *flat) {
     if (!flat) return fail(GNN_ERR_BAD_ARG, "null input");
+    if (dev == h->W) h->slab_valid = false; // first-layer sums made with the old weights
     std::vector<float> tmp;
     pack_params(h, flat, tmp);
     HIP_TRY(hipMemcpyAsync(dev, tmp.data(), sizeof(float) * (size_t)h->n_pad, hipMemcpyHostToDevice, h->stream));
@@ -846,7 +960,7 @@ int gnn_mlp_destroy(gnn_mlp_t *h) {
     for (float *p : h->act) fr(p);
     for (float *p : h->delta) fr(p);
     fr(h->logits); fr(h->prob); fr(h->ybuf); fr(h->lossv); fr(h->labels); fr(h->idxbuf);
-    fr(h->stage_x); fr(h->stage_y); fr(h->stage_out); fr(h->DX); fr(h->DY);
+    fr(h->stage_x); fr(h->stage_y); fr(h->stage_out); fr(h->DX); fr(h->DY); fr(h->slabs);
     if (h->tr_exec) (void)hipGraphExecDestroy(h->tr_exec);
     if (h->tr_graph) (void)hipGraphDestroy(h->tr_graph);
     for (TimerClass &t : h->timers) {
@@ -917,7 +1031,7 @@ int gnn_mlp_compute_gradient(gnn_mlp_t *h, const double *X, const double *Y, int
     const int Lm = h->L - 1;
     TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
     TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
-    do_gradient(h, h->act[0], h->ybuf, B, false, 0.f, 0.f);
+    do_gradient(h, h->act[0], h->ybuf, B, false, 0.f, 0.f, false);
     TRY_LAUNCHES(h);
     return GNN_OK;
 }
@@ -940,7 +1054,8 @@ int gnn_mlp_gradient_step(gnn_mlp_t *h, const double *X, const double *Y, int B,
     TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
     // the staging buffers are reused by the next call: pageable hipMemcpyAsync has returned
     // only once the host data was consumed, and the convert kernels are stream-ordered.
-    return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum);
+    h->have_next = false; // (a hint refers to dataset rows; this batch came from the host)
+    return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum, false);
 }
 
 int gnn_mlp_get_weights(gnn_mlp_t *h, double *flat) { TRY(check_handle(h)); return get_flat(h, h->W, flat); }
@@ -1037,6 +1152,7 @@ static int alloc_dataset(gnn_mlp *h, int64_t N) {
     if (h->DX) { (void)hipFree(h->DX); h->DX = nullptr; }
     if (h->DY) { (void)hipFree(h->DY); h->DY = nullptr; }
     h->dataset_n = 0;
+    h->slab_valid = false; h->have_next = false; // they name rows of the old dataset
     const size_t rows = (size_t)N + PAD; // PAD zero rows behind the last sample: a batch's padding rows read them
     TRY(dev_alloc(&h->DX, rows * h->ld[0], h->stream));
     TRY(dev_alloc(&h->DY, rows * h->ld[h->L - 1], h->stream));
@@ -1105,7 +1221,12 @@ int gnn_mlp_gradient_step_range(gnn_mlp_t *h, int64_t first, int B, double step,
     TRY(check_step_args(h, B, step, noise));
     TRY(check_range(h, first, B));
     return step_on_rows(h, h->DX + (size_t)first * h->ld[0], h->DY + (size_t)first * h->ld[h->L - 1], B, step,
-                        momentum);
+                        momentum, true);
+}
+
+// the next gradient computation runs on dataset rows [row0, row0 + B)
+static void hint_range(gnn_mlp *h, int64_t row0, int B) {
+    h->have_next = true; h->next_a0 = h->DX + (size_t)row0 * h->ld[0]; h->next_idx = nullptr; h->next_B = B;
 }
 
 int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double step, double momentum) {
@@ -1133,14 +1254,24 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
         if (!hit) {
             if (h->tr_exec) { (void)hipGraphExecDestroy(h->tr_exec); h->tr_exec = nullptr; }
             if (h->tr_graph) { (void)hipGraphDestroy(h->tr_graph); h->tr_graph = nullptr; }
+            if (h->chain) { // two-launch path: the pass is captured as a closed chain -- every step, the last one too, also
+                            // makes the first-layer slabs of the batch after it -- so its first batch's slabs must exist before
+                const float *a0 = h->DX + (size_t)(fb * B) * h->ld[0];
+                if (!slabs_hold(h, a0, nullptr, B)) {
+                    const NextBatch self{a0, nullptr, B};
+                    launch_tile_step(h, 0, 0, &self, a0, B, 0.f, 0.f);
+                    slabs_now_hold(h, self);
+                }
+            }
             if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 const int t0 = h->time;
                 int rc = GNN_OK;
                 for (int64_t b = 0; b < nb && rc == GNN_OK; b++) {
                     const int64_t row0 = ((fb + b) % nb) * B;
-                    rc = step_on_rows(h, h->DX + (size_t)row0 * h->ld[0], h->DY + (size_t)row0 * h->ld[h->L - 1], B, step, momentum);
+                    hint_range(h, ((fb + b + 1) % nb) * B, B);
+                    rc = step_on_rows(h, h->DX + (size_t)row0 * h->ld[0], h->DY + (size_t)row0 * h->ld[h->L - 1], B, step, momentum, true);
                 }
-                h->time = t0; // captured, not executed
+                h->time = t0; // captured, not executed (the slabs of batch fb, made above, are still the current ones)
                 hipGraph_t g = nullptr;
                 const hipError_t e = hipStreamEndCapture(h->stream, &g);
                 if (rc == GNN_OK && e == hipSuccess && g && hipGraphInstantiate(&h->tr_exec, g, nullptr, nullptr, 0) == hipSuccess) {
@@ -1155,6 +1286,14 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
                 (void)hipGetLastError();
             }
         }
+        if (h->tr_exec && h->chain && n_steps - s >= nb) { // a replay starts from batch fb's slabs and leaves them behind again
+            const float *a0 = h->DX + (size_t)(fb * B) * h->ld[0];
+            if (!slabs_hold(h, a0, nullptr, B)) {
+                const NextBatch self{a0, nullptr, B};
+                launch_tile_step(h, 0, 0, &self, a0, B, 0.f, 0.f);
+                slabs_now_hold(h, self);
+            }
+        }
         while (h->tr_exec && n_steps - s >= nb) {
             HIP_TRY(hipGraphLaunch(h->tr_exec, h->stream));
             h->time += (int)nb;
@@ -1163,8 +1302,9 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
     }
     for (; s < n_steps; s++) {
         const int64_t row0 = ((first / B + s) % nb) * B;
+        if (s + 1 < n_steps) hint_range(h, ((first / B + s + 1) % nb) * B, B); // the step's tile kernel also starts the next step
         TRY(step_on_rows(h, h->DX + (size_t)row0 * h->ld[0], h->DY + (size_t)row0 * h->ld[h->L - 1], B, step,
-                         momentum));
+                         momentum, true));
     }
     return GNN_OK;
 }
@@ -1186,6 +1326,7 @@ int gnn_mlp_gradient_step_indexed(gnn_mlp_t *h, const int32_t *idx, int B, doubl
     for (int i = 0; i < B; i++)
         if (idx[i] < 0 || idx[i] >= h->dataset_n) return fail(GNN_ERR_BAD_ARG, "sample index out of range");
     HIP_TRY(hipMemcpyAsync(h->idxbuf, idx, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    h->slab_valid = false; h->have_next = false; // idxbuf is reused: its address does not identify a batch
     return step_on_device_indices(h, h->idxbuf, B, step, momentum);
 }
 
@@ -1272,12 +1413,12 @@ static int step_on_device_indices(gnn_mlp *h, const int32_t *d_idx, int B, doubl
         // fused path: its three kernels read the sampled rows of the resident dataset through the
         // index vector themselves (two gather launches cost 14 us of a 33-us step)
         h->cur_idx = d_idx;
-        const int rc = step_on_rows(h, h->DX, h->DY, B, step, momentum);
+        const int rc = step_on_rows(h, h->DX, h->DY, B, step, momentum, true);
         h->cur_idx = nullptr;
         return rc;
     }
     launch_gather(h, d_idx, B);
-    return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum);
+    return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum, false);
 }
 
 int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step, double momentum,
@@ -1326,11 +1467,16 @@ int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int ba
         const hipError_t e = hipMemcpyAsync(d_idx + (size_t)i0 * batch, idx.data() + (size_t)i0 * batch,
                                             (size_t)(i1 - i0) * batch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
         if (e != hipSuccess) { rc = fail(GNN_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); break; }
-        for (int i = i0; i < i1 && rc == GNN_OK; i++)
+        for (int i = i0; i < i1 && rc == GNN_OK; i++) {
+            if (h->chain && i + 1 < i1) { // the next draw of this chunk is already on the device
+                h->have_next = true; h->next_a0 = h->DX; h->next_idx = d_idx + (size_t)(i + 1) * batch; h->next_B = cnt[i + 1];
+            }
             rc = step_on_device_indices(h, d_idx + (size_t)i * batch, cnt[i], step, momentum);
+        }
     }
     producer.join(); // (on an early exit the sampler still finishes its draws: its state stays well defined)
     (void)hipStreamSynchronize(h->stream); // idx (host) and d_idx are released below
+    h->slab_valid = false; h->have_next = false; // (they may name rows through d_idx)
     if (d_idx) (void)hipFree(d_idx);
     return rc;
 }
@@ -1367,8 +1513,16 @@ int gnn_mlp_compute_gradient_range(gnn_mlp_t *h, int64_t first, int B) {
     TRY(check_range(h, first, B));
     const float *a0 = h->DX + (size_t)first * h->ld[0];
     maybe_specialize(h);
-    do_gradient(h, a0, h->DY + (size_t)first * h->ld[h->L - 1], B, false, 0.f, 0.f);
+    do_gradient(h, a0, h->DY + (size_t)first * h->ld[h->L - 1], B, false, 0.f, 0.f, true);
     TRY_LAUNCHES(h);
+    return GNN_OK;
+}
+
+int gnn_mlp_hint_next_range(gnn_mlp_t *h, int64_t first, int B) {
+    TRY(check_handle(h));
+    TRY(check_batch(h, B));
+    TRY(check_range(h, first, B));
+    hint_range(h, first, B);
     return GNN_OK;
 }
 
@@ -1376,10 +1530,18 @@ int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentu
     TRY(check_handle(h));
     if (B_global <= 0) return fail(GNN_ERR_BAD_ARG, "B_global must be positive");
     if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
-    const int64_t n4 = h->n_pad / 4;
-    hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(n4)), dim3(256), 0, h->stream,
-                       reinterpret_cast<float4 *>(h->W), reinterpret_cast<float4 *>(h->V),
-                       reinterpret_cast<const float4 *>(h->G), n4, (float)(step / (double)B_global), (float)momentum);
+    NextBatch nb{};
+    if (h->chain && take_next(h, &nb)) {
+        // the update by weight tiles, each tile going straight on to the next batch's first-layer slab
+        launch_tile_step(h, 2, 2, &nb, nullptr, PAD, (float)(step / (double)B_global), (float)momentum);
+        slabs_now_hold(h, nb);
+    } else {
+        const int64_t n4 = h->n_pad / 4;
+        launch_timed(h, GNN_K_UPDATE, sgd_momentum_kernel, dim3(grid_for(n4)), dim3(256), 0,
+                     SgdParams{reinterpret_cast<float4 *>(h->W), reinterpret_cast<float4 *>(h->V),
+                               reinterpret_cast<const float4 *>(h->G), n4, (float)(step / (double)B_global), (float)momentum});
+        h->slab_valid = false; h->have_next = false;
+    }
     h->time++;
     TRY_LAUNCHES(h);
     return GNN_OK;
@@ -1421,6 +1583,7 @@ int gnn_mlp_specialize(gnn_mlp_t *h) {
     return GNN_OK;
 }
 int gnn_mlp_specialization(const gnn_mlp_t *h) { return h ? h->specialization : -1; }
+int gnn_mlp_step_launches(const gnn_mlp_t *h) { return !h ? -1 : h->chain ? 2 : h->mid4 ? 3 : 0; }
 
 // ---- measurement ---------------------------------------------------------------------------
 int gnn_mlp_timing_enable(gnn_mlp_t *h, int on) {
@@ -1433,7 +1596,7 @@ int gnn_mlp_timing_enable(gnn_mlp_t *h, int on) {
 
 int gnn_mlp_timing_read(gnn_mlp_t *h, int which, double *mean_us, int64_t *count) {
     TRY(check_handle(h));
-    if (which < 0 || which > 3 || !mean_us || !count) return fail(GNN_ERR_BAD_ARG, "bad timing query");
+    if (which < 0 || which > 4 || !mean_us || !count) return fail(GNN_ERR_BAD_ARG, "bad timing query");
     HIP_TRY(hipStreamSynchronize(h->stream));
     TimerClass &t = h->timers[which];
     double total = 0.0;

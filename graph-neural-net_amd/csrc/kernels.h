@@ -58,6 +58,14 @@ __device__ __forceinline__ float act_prime_from_a(int kind, float a) {
     }
 }
 
+// adj = ((step*G)/B) + (momentum*prev), SCE:333, with step/B folded into one factor.  ONE spelling
+// for every kernel that updates -- an explicit fma of the first product onto the rounded second --
+// so that the fused update, the flat update after an all-reduce and the tile-owner kernel give the
+// same bits for the same G (left to the compiler, `a*b + c*d` contracts differently from kernel to kernel).
+__device__ __forceinline__ float sgd_adj(float step_over_b, float g, float momentum, float prev) {
+    return __builtin_fmaf(step_over_b, g, momentum * prev);
+}
+
 // ------------------------------------------------------------------------------------------
 // GEMM  C[M x N] = opA(A)[M x K] . opB(B)[K x N]   with a fused epilogue.
 //   A_KC: A element (m,k) at A[m*lda + k]   (k contiguous)  else at A[k*lda + m]
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     else if (EPI == EPI_ACT) out0[j] = live ? act_fn(p.act, v[j]) : 0.f;
                     else if (EPI == EPI_DACT) out0[j] = live ? v[j] * act_prime_from_a(p.act, aux[j]) : 0.f;
                     else { // EPI_SGD: ((step*G)/B) + (momentum*prev), SCE:333; padding elements stay as they are (zeros)
-                        const float adj = p.step_over_b * v[j] + p.momentum * vold[j];
+                        const float adj = sgd_adj(p.step_over_b, v[j], p.momentum, vold[j]);
                         out0[j] = live ? wold[j] - adj : wold[j];
                         out1[j] = live ? adj : vold[j];
                     }
@@ -468,19 +476,22 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
 //   adj = (step*G)/B + momentum*prev ; W -= adj ; prev = adj
 // Padding elements have G = 0 and prev = 0, so they stay exactly 0.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sgd_momentum_kernel(float4 *__restrict__ W, float4 *__restrict__ V,
-                                                          const float4 *__restrict__ G, int64_t n4,
-                                                          float step_over_b, float momentum) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float4 g = G[i];
-        float4 v = V[i], w = W[i];
-        v.x = step_over_b * g.x + momentum * v.x;
-        v.y = step_over_b * g.y + momentum * v.y;
-        v.z = step_over_b * g.z + momentum * v.z;
-        v.w = step_over_b * g.w + momentum * v.w;
+struct SgdParams {
+    float4 *W; float4 *V; const float4 *G;
+    int64_t n4;
+    float step_over_b, momentum;
+};
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdParams p) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n4; i += (int64_t)gridDim.x * 256) {
+        const float4 g = p.G[i];
+        float4 v = p.V[i], w = p.W[i];
+        v.x = sgd_adj(p.step_over_b, g.x, p.momentum, v.x);
+        v.y = sgd_adj(p.step_over_b, g.y, p.momentum, v.y);
+        v.z = sgd_adj(p.step_over_b, g.z, p.momentum, v.z);
+        v.w = sgd_adj(p.step_over_b, g.w, p.momentum, v.w);
         w.x -= v.x; w.y -= v.y; w.z -= v.z; w.w -= v.w;
-        V[i] = v;
-        W[i] = w;
+        p.V[i] = v;
+        p.W[i] = w;
     }
 }
 

@@ -120,7 +120,12 @@ struct Mid4Params {
     int inner_act, last_act;     // inner_act is read only by kernels built with ACT = -1
     unsigned long long *stamps;  // STAMP builds only
     const int32_t *row_idx;      // optional: expected row of batch row r is Y row row_idx[r] (sampled batches)
+    // SLABS kernels: A_1 = f(sum of the K slabs of the first-layer sums) instead of reading act[1];
+    // slab s of batch row b at slabs[(s * slab_rows + b) * ld[1]] (tile_step_kernel.h)
+    const float *slabs; int slab_rows; int n_slabs;
 };
+
+constexpr int MID4_MAX_SLABS = 16;
 
 // NL > 0: the layer COUNT is a compile-time constant (extents stay kernel arguments), so the
 // per-layer loops unroll with constant trip counts and constant kernarg offsets; NL = 0: any L.
@@ -239,7 +244,8 @@ __device__ __forceinline__ void rowblock_product(const float *A_img, int lda, co
 }
 
 // NSLOT > 0: static shape, the number of weight slabs (Mid4Plan::st_total); 0: runtime extents
-template <int NL, int ACT_T, int OUTK, bool BACKWARD, bool STAMP, int NSLOT>
+// NS: 0 = A_1 is read from act[1]; > 0 = that many first-layer K slabs (static shape); < 0 = p.n_slabs of them
+template <int NL, int ACT_T, int OUTK, bool BACKWARD, bool STAMP, int NSLOT, int NS>
 __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     const int ACT = (ACT_T >= 0) ? ACT_T : p.inner_act;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -261,7 +267,36 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     const bool a1_on = t < 4 * q1, y_on = p.Y != nullptr && NT_ - 1 - t < 4 * qy; // Y: the LAST threads
     const int a1_r = t / q1, a1_q = t - a1_r * q1, y_e = NT_ - 1 - t, y_r = y_e / qy, y_q = y_e - y_r * qy;
     // (lanes without an element re-read element 0 and never store it)
-    f32x4 a1v = *reinterpret_cast<const f32x4 *>(p.act[1] + (a1_on ? (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4 : (size_t)0));
+    f32x4 a1v = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NSV = NS > 0 ? NS : (NS < 0 ? MID4_MAX_SLABS : 1);
+    f32x4 zs[NSV];
+    const int ns = NS > 0 ? NS : (NS < 0 ? p.n_slabs : 0); // block-uniform
+    if constexpr (NS == 0) {
+        a1v = *reinterpret_cast<const f32x4 *>(p.act[1] + (a1_on ? (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4 : (size_t)0));
+    } else {
+        const float *zp = p.slabs + (a1_on ? (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4 : (size_t)0);
+        const size_t sstride = (size_t)p.slab_rows * m.ld[1];
+#pragma unroll
+        for (int s_ = 0; s_ < NSV; s_++) {
+            zs[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (s_ < ns) zs[s_] = *reinterpret_cast<const f32x4 *>(zp + s_ * sstride);
+        }
+    }
+    // slabs in slab order, then f; rows past the batch and columns past d_1 are zeros (f(0) != 0 for the sigmoid)
+    auto finish_a1 = [&]() {
+        if constexpr (NS != 0) {
+#pragma unroll
+            for (int s_ = 0; s_ < NSV; s_++) asm volatile("" : "+v"(zs[s_])); // every slab load issued before the first add waits
+            f32x4 z = zs[0];
+#pragma unroll
+            for (int s_ = 1; s_ < NSV; s_++)
+                if (s_ < ns) z += zs[s_];
+            const bool lrow = row0 + a1_r < p.B;
+#pragma unroll
+            for (int j = 0; j < 4; j++) a1v[j] = (lrow && a1_q * 4 + j < m.d[1]) ? act_fn(ACT, z[j]) : 0.f;
+            if (a1_on) *reinterpret_cast<f32x4 *>(p.act[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) = a1v; // the gradient kernel reads A_1
+        }
+    };
     size_t y_row = (size_t)(row0 + y_r);
     if (y_on && p.row_idx) y_row = row0 + y_r < p.B ? (size_t)p.row_idx[row0 + y_r] : 0; // rows past the batch are masked below
     f32x4 yv = *reinterpret_cast<const f32x4 *>((p.Y ? p.Y : p.act[1]) + (y_on ? y_row * p.ldy + y_q * 4 : (size_t)0));
@@ -302,6 +337,7 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
             asm volatile("" : "+v"(a1v), "+v"(yv));
 #pragma unroll
             for (int i = 0; i < NSLOT; i++) asm volatile("" : "+v"(v[i]));
+            finish_a1();
             if (a1_on) *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
             if (y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv;
 #pragma unroll
@@ -347,6 +383,7 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                         for (int i = 0; i < MAXF; i++) asm volatile("" : "+v"(v[i])); // pin the loads (see above)
                         if (j == 1 && tb == 0) { // the first weight loads are in flight: now the rows
                             asm volatile("" : "+v"(a1v), "+v"(yv));
+                            finish_a1();
                             if (a1_on) *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
                             if (y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv;
                         }
@@ -648,15 +685,18 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     } // pass
 }
 
-template <class SH, int ACT, int OUTK, bool BACKWARD, bool STAMP = false>
+// SLABS: A_1 comes as K slabs from tile_step_kernel (64 input neurons per slab) instead of from act[1]
+template <class SH, int ACT, int OUTK, bool BACKWARD, bool STAMP = false, bool SLABS = false>
 __global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
     if constexpr (SH::is_static) {
         // a LOCAL constexpr object: every member access with a compile-time index folds to an
         // immediate (a namespace-scope constant would be loaded from memory)
         constexpr Mid4Plan m = SH::make();
-        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, m.st_total>(m, p);
+        constexpr int ns = SLABS ? (m.ld[0] + 63) / 64 : 0;
+        static_assert(ns <= MID4_MAX_SLABS, "too many first-layer slabs for the register-resident sum");
+        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, m.st_total, ns>(m, p);
     } else {
-        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, 0>(p.plan, p);
+        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, 0, SLABS ? -1 : 0>(p.plan, p);
     }
 }
 

@@ -1,0 +1,251 @@
+// tile_step_kernel.h -- the "tile owner" kernel of the small-net path: TWO launches per gradientStep.
+//
+// A gradientStep (SCE:297-346) has two all-to-all exchanges: the first layer is tiled over the
+// columns of W_0 while the chain A_1 -> delta_1 is per batch row, and the weight gradient
+// G_l = A_l^T . delta_{l+1} (SCE:253-258, 279-283 summed over the batch by SCE:305-322) is tiled over
+// the weight matrix again.  The hop from one step's update to the next step's first layer is NOT
+// an exchange: the workgroup that has just updated a tile of W_0 (SCE:333-339) holds exactly the
+// weights the next batch's product A_0 . W_0 (SCE:187-192) needs from that tile.  So this kernel,
+// for one 64 x 16 tile of one layer's weight matrix:
+//
+//   GSRC = 1  G = A_l^T . delta_{l+1} over the batch rows            (MFMA, K = batch)
+//   GSRC = 2  G = the tile of the all-reduced gradient buffer        (data parallel)
+//   GDST = 1  stores G                                               (data parallel: the all-reduce follows)
+//   GDST = 2  adj = (step*G)/B + momentum*prev ; W -= adj ; prev = adj
+//   FWD       layer 0 only: Zp[b][n] = sum over the tile's 64 input neurons of A_0'[b][m] . W_0[m][n]
+//             for the NEXT batch A_0' with the tile's NEW weights -- one K slab of the next step's
+//             first-layer sums.  middle4_kernel adds the ceil(d_0/64) slabs in slab order (fixed:
+//             results do not depend on dispatch order) and applies f.
+//   GSRC = 0, GDST = 0, FWD: the slabs of a batch from the weights as they are (start of a chain).
+//
+// One step is then { middle4_kernel ; tile_step_kernel } instead of { fwd_first ; middle4 ;
+// grad_update }: one dependent launch (~2.5 us fixed on this chip) and the cold re-read of W_0 less.
+// The slab arithmetic is the same whether a slab was made by the previous step's tile kernel or by a
+// forward-only launch, so a sequence of steps gives bitwise the same weights however it is cut into
+// calls.
+//
+// All contractions on v_mfma_f32_16x16x4_f32 (exact f32).  8 waves:
+//   gradient: wave -> (m tile of 16 = wave & 3, half of every 128-row K chunk = wave >> 2)
+//   forward : wave -> 16 batch rows of every 128-row chunk; K = the tile's 64 input neurons
+#pragma once
+#include "fused_kernels.h"
+
+namespace gnn {
+
+constexpr int TS_TM = 64, TS_TN = 16, TS_THREADS = 512, TS_KC = 128;
+constexpr int TS_MAX_SLABS = 16; // middle4_kernel keeps one float4 per slab in registers
+
+struct TileStepParams {
+    GradLayer layer[MAX_LAYERS]; // tiling in 64 x 16 tiles; block_begin per layer
+    int n_layers;
+    int K, k_true;               // padded / live batch rows of the CURRENT batch (gradient)
+    float step_over_b, momentum;
+    const int32_t *row_idx;      // optional, layer 0: batch row k of A_0 is dataset row row_idx[k]
+    // next batch (FWD), layer 0 only
+    const float *An; int ldan;   // A_0' rows
+    const int32_t *next_idx;     // optional row indices of the next batch
+    int next_rows, next_K;       // live / padded rows of the next batch
+    float *slabs;                // [n slabs][slab_rows][ldz]
+    int slab_rows, ldz;
+};
+
+template <int GSRC, int GDST, bool FWD>
+__global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p) {
+    constexpr int LDA = TS_TM + 16;  // gradient A image [k][m]: row stride = 16 (mod 32) floats
+    constexpr int LDD = TS_TN;       // delta image [k][n]: 16 floats (lanes 16-31 land on banks 16-31)
+    constexpr int LDN = TS_TM + 8;   // forward A' image [b][m]: the b128 reads of a 16-lane group (rows fr, k offsets 4*fq) hit 16 different 16-B slots
+    constexpr int LDW = TS_TN + 4;   // weight tile / partial tiles [m][n]
+    constexpr int A_FLOATS = TS_KC * (LDA > LDN ? LDA : LDN);
+    static_assert(2 * TS_TM * LDW <= A_FLOATS, "the two partial G tiles reuse the A image");
+    __shared__ __attribute__((aligned(16))) float sA[A_FLOATS];         // A chunk; then the two K halves of G; then the A' chunks
+    __shared__ __attribute__((aligned(16))) float sD[TS_KC * LDW];       // delta chunk [128][16]; later the slab tile [128][20]
+    __shared__ __attribute__((aligned(16))) float sW[TS_TM * LDW];       // the tile's (new) weights
+    float *sC = sA;                                                      // (55 KB in all: two workgroups per CU)
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_LAYERS; i++)
+        if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].block_begin) li = i;
+    const GradLayer &L = p.layer[li];
+    int tm, tn;
+    if (!L.tiling.tile_of(blockIdx.x - L.block_begin, tm, tn)) return;
+    const int m0 = tm * TS_TM, n0 = tn * TS_TN;
+    const bool fwd = FWD && li == 0; // block-uniform
+
+    // this thread's 16 B of the weight tile: row er, columns 4*eq .. 4*eq+3 (threads 0..255)
+    const int er = t >> 2, eq = t & 3;
+    const bool e_ok = t < 256 && (m0 + er < L.M);
+    const size_t e_off = (size_t)(m0 + er) * L.ldd + n0 + eq * 4;
+
+    // ---- everything this block reads first, all loads in flight together ------------------------
+    // gradient operands of the first K chunk
+    float4 va[4], vd;
+    const int kc0 = (p.K < TS_KC) ? p.K : TS_KC;
+    if (GSRC == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = t + i * TS_THREADS, k = idx >> 4, q = idx & 15;
+            va[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kc0 && m0 + q * 4 < L.M) {
+                size_t a_row = (size_t)k;
+                bool live = true;
+                if (li == 0 && p.row_idx) { live = k < p.k_true; a_row = live ? (size_t)p.row_idx[k] : 0; }
+                if (live) va[i] = *reinterpret_cast<const float4 *>(L.A + a_row * L.lda + m0 + q * 4);
+            }
+        }
+        {
+            const int k = t >> 2, q = t & 3;
+            vd = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kc0) vd = *reinterpret_cast<const float4 *>(L.D + (size_t)k * L.ldd + n0 + q * 4);
+        }
+    }
+    float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f), v_old = w_old, g_in = w_old;
+    if (e_ok) {
+        if (GDST == 2 || FWD) w_old = *reinterpret_cast<const float4 *>(L.W + e_off);
+        if (GDST == 2) v_old = *reinterpret_cast<const float4 *>(L.V + e_off);
+        if (GSRC == 2) g_in = *reinterpret_cast<const float4 *>(L.G + e_off);
+    }
+    // first chunk of the next batch's rows (held in registers until the A image is free)
+    float4 vn[4];
+    auto load_next = [&](int b0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = t + i * TS_THREADS, b = idx >> 4, q = idx & 15;
+            vn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b0 + b < p.next_rows && m0 + q * 4 < L.M) {
+                const size_t row = p.next_idx ? (size_t)p.next_idx[b0 + b] : (size_t)(b0 + b);
+                vn[i] = *reinterpret_cast<const float4 *>(p.An + row * p.ldan + m0 + q * 4);
+            }
+        }
+    };
+    if (fwd) load_next(0);
+
+    // ---- gradient tile: G[m][n] = sum_k A[k][m] D[k][n] ------------------------------------------
+    float4 g = g_in;
+    if (GSRC == 1) {
+        const int mt = wave & 3, kh = wave >> 2;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < p.K; k0 += TS_KC) {
+            const int kc = (p.K - k0 < TS_KC) ? p.K - k0 : TS_KC; // a multiple of 16
+            if (k0) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int idx = t + i * TS_THREADS, k = idx >> 4, q = idx & 15;
+                    va[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < kc && m0 + q * 4 < L.M) {
+                        size_t a_row = (size_t)(k0 + k);
+                        bool live = true;
+                        if (li == 0 && p.row_idx) { live = k0 + k < p.k_true; a_row = live ? (size_t)p.row_idx[k0 + k] : 0; }
+                        if (live) va[i] = *reinterpret_cast<const float4 *>(L.A + a_row * L.lda + m0 + q * 4);
+                    }
+                }
+                const int k = t >> 2, q = t & 3;
+                vd = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kc) vd = *reinterpret_cast<const float4 *>(L.D + (size_t)(k0 + k) * L.ldd + n0 + q * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int idx = t + i * TS_THREADS, k = idx >> 4, q = idx & 15;
+                *reinterpret_cast<float4 *>(&sA[k * LDA + q * 4]) = va[i];
+            }
+            *reinterpret_cast<float4 *>(&sD[(t >> 2) * LDD + (t & 3) * 4]) = vd;
+            __syncthreads();
+            const float *ap = &sA[fq * LDA + mt * 16 + fr];
+            const float *dp = &sD[fq * LDD + fr];
+            const int kbeg = kh * (kc >> 1), kend = kbeg + (kc >> 1); // kc/2 is a multiple of 8
+            int kk = kbeg;
+            for (; kk + 32 <= kend; kk += 32) { // 8 MFMAs per trip, the trip's 16 LDS reads issued first
+                float a[8], d[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { a[j] = ap[(kk + 4 * j) * LDA]; d[j] = dp[(kk + 4 * j) * LDD]; }
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], d[j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1], d[j + 1], acc1, 0, 0, 0);
+                }
+            }
+            for (; kk < kend; kk += 4)
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * LDA], dp[kk * LDD], acc0, 0, 0, 0);
+        }
+        const f32x4 acc = acc0 + acc1;
+        __syncthreads(); // every wave has finished reading the A image
+#pragma unroll
+        for (int r = 0; r < 4; r++) sC[(kh * TS_TM + mt * 16 + fq * 4 + r) * LDW + fr] = acc[r];
+        __syncthreads();
+        if (t < 256) {
+            const float4 g0 = *reinterpret_cast<const float4 *>(&sC[er * LDW + eq * 4]);
+            const float4 g1 = *reinterpret_cast<const float4 *>(&sC[(TS_TM + er) * LDW + eq * 4]);
+            g = make_float4(g0.x + g1.x, g0.y + g1.y, g0.z + g1.z, g0.w + g1.w);
+        }
+    }
+
+    // ---- store G, or the momentum update (SCE:333-339) -------------------------------------------
+    float4 w_new = w_old;
+    if (GDST == 1) {
+        if (e_ok) *reinterpret_cast<float4 *>(L.G + e_off) = g;
+    } else if (GDST == 2) {
+        float4 adj; // ((step*G)/B) + (momentum*prev)
+        adj.x = sgd_adj(p.step_over_b, g.x, p.momentum, v_old.x);
+        adj.y = sgd_adj(p.step_over_b, g.y, p.momentum, v_old.y);
+        adj.z = sgd_adj(p.step_over_b, g.z, p.momentum, v_old.z);
+        adj.w = sgd_adj(p.step_over_b, g.w, p.momentum, v_old.w);
+        w_new = make_float4(w_old.x - adj.x, w_old.y - adj.y, w_old.z - adj.z, w_old.w - adj.w);
+        if (e_ok) {
+            *reinterpret_cast<float4 *>(L.W + e_off) = w_new;
+            *reinterpret_cast<float4 *>(L.V + e_off) = adj;
+        }
+    }
+    if (!fwd) return;
+
+    // ---- the next batch's first-layer sums over this tile's 64 input neurons ---------------------
+    if (t < 256) *reinterpret_cast<float4 *>(&sW[er * LDW + eq * 4]) = e_ok ? w_new : make_float4(0.f, 0.f, 0.f, 0.f);
+    float *slab = p.slabs + (size_t)tm * p.slab_rows * p.ldz;
+    for (int b0 = 0; b0 < p.next_K; b0 += TS_KC) {
+        if (b0) load_next(b0);
+        __syncthreads(); // the A image (or the previous chunk's A' image and slab tile) is free; sW is written
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = t + i * TS_THREADS, b = idx >> 4, q = idx & 15;
+            *reinterpret_cast<float4 *>(&sA[b * LDN + q * 4]) = vn[i];
+        }
+        __syncthreads();
+        // wave -> 16 batch rows; A' is k-contiguous: one b128 per 16 k (slot q of MFMA j holds k = 16c + 4q + j)
+        if (b0 + wave * 16 < p.next_K) {
+            f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+            const float *arow = &sA[(wave * 16 + fr) * LDN + 4 * fq];
+            const float *wcol = &sW[(4 * fq) * LDW + fr];
+            f32x4 a[4];
+            float b[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                a[c] = *reinterpret_cast<const f32x4 *>(arow + c * 16);
+#pragma unroll
+                for (int j = 0; j < 4; j++) b[c][j] = wcol[(c * 16 + j) * LDW];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (c & 1) z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], z1, 0, 0, 0);
+                    else z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], z0, 0, 0, 0);
+                }
+            }
+            const f32x4 z = z0 + z1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) sD[(wave * 16 + fq * 4 + r) * LDW + fr] = z[r];
+        }
+        __syncthreads();
+        {   // one 16-B store per thread: row b = t / 4, columns 4*(t%4)..
+            const int b = t >> 2, q = t & 3;
+            if (b0 + b < p.next_K)
+                *reinterpret_cast<float4 *>(slab + (size_t)(b0 + b) * p.ldz + n0 + q * 4) =
+                    *reinterpret_cast<const float4 *>(&sD[b * LDW + q * 4]);
+        }
+    }
+}
+
+} // namespace gnn

@@ -68,6 +68,11 @@ class HipEngine:
     def apply_update(self, B_global, step, momentum):
         self.net.apply_update(B_global, step, momentum)
 
+    def hint_next_range(self, first, B):
+        """The next compute_gradient_range will be on local rows [first, first+B): the update kernel
+        then also starts that step (gnn_mlp_hint_next_range; speed only)."""
+        self.net.hint_next_range(first, B)
+
     def weights_checksum(self):
         w = self.net.get_weights()
         return np.array([w.sum(), np.abs(w).sum()])
@@ -82,11 +87,14 @@ class DataParallelStep:
         self.world = dist_module.get_world_size(group) if dist_module is not None else 1
         self.rank = dist_module.get_rank(group) if dist_module is not None else 0
 
-    def step(self, first, B_local, step, momentum):
+    def step(self, first, B_local, step, momentum, next_first=None):
         """One global gradientStep; every rank passes its own local rows.  The three stages are
-        ordered by ONE stream: the engine's (CPU engines have none)."""
+        ordered by ONE stream: the engine's (CPU engines have none).  `next_first`: the local rows of
+        the NEXT step, when the caller knows them (same B_local) -- results do not depend on it."""
         ctx = self.engine.stream_context() if hasattr(self.engine, "stream_context") else contextlib.nullcontext()
         with ctx:
+            if next_first is not None and hasattr(self.engine, "hint_next_range"):
+                self.engine.hint_next_range(next_first, B_local)
             self.engine.compute_gradient_range(first, B_local)
             B_global = B_local
             if self.dist is not None and (self.world > 1 or self.always_reduce):
@@ -117,16 +125,17 @@ class GraphedSteps:
         torch = torch_module
         self.stepper, self.torch, self.stream, self.n = stepper, torch, stream, len(firsts)
         self.graph = torch.cuda.CUDAGraph()
+        nxt = firsts[1:] + firsts[:1]     # the sequence is replayed as a cycle: every step names its successor
         with torch.cuda.stream(stream):   # one eager pass: lazy RCCL / allocator initialisation
-            for f in firsts:
-                stepper.step(f, B_local, step, momentum)
+            for f, fn in zip(firsts, nxt):
+                stepper.step(f, B_local, step, momentum, next_first=fn)
         stream.synchronize()
         net = stepper.engine.net
         t_before = net.time
         try:
             with torch.cuda.graph(self.graph, stream=stream):
-                for f in firsts:
-                    stepper.step(f, B_local, step, momentum)
+                for f, fn in zip(firsts, nxt):
+                    stepper.step(f, B_local, step, momentum, next_first=fn)
                 if inject_failure:   # test hook: a call that is not permitted while capturing, so the capture really fails
                     torch.cuda.synchronize()
         except Exception as e:

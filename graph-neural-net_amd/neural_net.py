@@ -252,6 +252,10 @@ class NeuralNet:
     def apply_update(self, B_global, step, momentum):
         _capi.check(self._lib.gnn_mlp_apply_update(self._h, int(B_global), float(step), float(momentum)))
 
+    def hint_next_range(self, first, B):
+        """The next gradient computation will run on dataset rows [first, first+B) (speed only)."""
+        _capi.check(self._lib.gnn_mlp_hint_next_range(self._h, int(first), int(B)))
+
     def synchronize(self):
         _capi.check(self._lib.gnn_mlp_synchronize(self._h))
 
@@ -272,6 +276,11 @@ class NeuralNet:
     def specialization(self):
         """0 generic kernels, 1 prebuilt instantiation, 2 instantiated at run time."""
         return self._lib.gnn_mlp_specialization(self._h)
+
+    @property
+    def step_launches(self):
+        """2 two-launch path, 3 fused three-launch path, 0 per-layer GEMMs."""
+        return self._lib.gnn_mlp_step_launches(self._h)
 
     # -- measurement --------------------------------------------------------------------------
     def timing_enable(self, on=True):

@@ -190,6 +190,11 @@ int gnn_mlp_compute_gradient_range(gnn_mlp_t *h, int64_t first, int B_local);
 int gnn_mlp_compute_gradient(gnn_mlp_t *h, const double *X, const double *Y, int B_local);
 /* SCE:324-344 on the (all-reduced) gradient buffer with batchSize = B_global. */
 int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentum);
+/* Optional: names the dataset rows [first, first+B) that the NEXT gradient computation will run on
+ * (the loop NNT:82-85 knows its next batch).  On the small-net path the kernel that updates the
+ * weights then also forms that batch's first-layer sums, tile by tile, from the weights it has just
+ * written (one dependent launch less per step).  Good for one update; results do not depend on it. */
+int gnn_mlp_hint_next_range(gnn_mlp_t *h, int64_t first, int B);
 int gnn_mlp_synchronize(gnn_mlp_t *h);
 /* A caller that captured steps into a hipGraph (stream capture on the stream given to
  * gnn_mlp_set_stream) replays device work the host-side `time` counter (SCE:343) does not see;
@@ -215,6 +220,10 @@ int gnn_mlp_recover_stream(gnn_mlp_t *h);
  * 2 = instantiated at run time. */
 int gnn_mlp_specialize(gnn_mlp_t *h);
 int gnn_mlp_specialization(const gnn_mlp_t *h);
+/* Kernel launches of one gradientStep inside a training loop on this net: 2 = the two-launch path
+ * (row-block kernel + tile-owner kernel, csrc/tile_step_kernel.h), 3 = first layer / row-block kernel /
+ * gradient+update, 0 = per-layer GEMMs (the count then depends on the layer count). */
+int gnn_mlp_step_launches(const gnn_mlp_t *h);
 
 /* ---- measurement support (bench.py) -------------------------------------------------------
  * Mean duration in microseconds of the kernel class `which` over the launches since the last
@@ -222,10 +231,12 @@ int gnn_mlp_specialization(const gnn_mlp_t *h);
  * (hipExtLaunchKernel start/stop events on the handle's stream), i.e. the quantity rocprofv3's
  * kernel trace reports; timing must be enabled first. */
 typedef enum {
-    GNN_K_FWD_GEMM0 = 0,  /* first forward GEMM  (B x d_0 x d_1) */
-    GNN_K_GRAD_GEMM0 = 1, /* first-layer weight-gradient GEMM (d_0 x d_1 x B) */
+    GNN_K_FWD_GEMM0 = 0,  /* first forward GEMM  (B x d_0 x d_1), as its own launch (inference; start of a step chain) */
+    GNN_K_GRAD_GEMM0 = 1, /* weight-gradient kernel (d_0 x d_1 x B ...): with the fused update, and on the two-launch
+                             path with the next batch's first-layer product */
     GNN_K_STEP = 2,       /* one whole gradient step (events recorded around the launches) */
-    GNN_K_MIDDLE = 3      /* fused path only: the per-row-block kernel between A_1 and delta_1 */
+    GNN_K_MIDDLE = 3,     /* fused path only: the per-row-block kernel between A_1 and delta_1 */
+    GNN_K_UPDATE = 4      /* data-parallel path: the momentum update after the all-reduce */
 } gnn_kernel_class;
 int gnn_mlp_timing_enable(gnn_mlp_t *h, int on);
 int gnn_mlp_timing_read(gnn_mlp_t *h, int which, double *mean_us, int64_t *count);

@@ -11,6 +11,8 @@ Tolerances (fp32 GEMMs on v_mfma_f32_16x16x4_f32 vs the fp64 serial loops):
   * argmax labels: bit-exact wherever the oracle's top-2 logit margin exceeds 1e-3;
     the fixtures have no sample below that margin (asserted).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -459,6 +461,58 @@ def test_train_range_graph_replay_equals_stepwise(gnn, monkeypatch):
     assert a.time == b.time == n + 2 * nb
     assert np.array_equal(a.get_weights(), b.get_weights())
     assert np.array_equal(a.get_momentum(), b.get_momentum())
+
+
+@pytest.mark.parametrize("dims,B,inner", [([784, 300, 100, 10], 128, LEAKY), ([784, 100, 50, 10], 32, SIGMOID),
+                                          ([200, 90, 40, 7], 150, TANH), ([64, 48, 10], 19, RELU)])
+def test_two_launch_step_chain(gnn, oracle_mod, monkeypatch, dims, B, inner):
+    """The two-launch path (csrc/tile_step_kernel.h: the kernel that updates a tile of W_0 also forms the next
+    batch's first-layer sums over that tile's 64 inputs; middle4 adds the K slabs in slab order) against
+    (1) the three-launch path GNN_MLP_CHAIN=0 (same arithmetic up to the summation order of the first layer),
+    (2) itself, cut into calls differently and with / without next-batch hints: BITWISE,
+    (3) the fp64 oracle."""
+    if os.environ.get("GNN_MLP_PATH"):
+        pytest.skip("path forced by the environment")
+    nb, n = 5, 12
+    X, Y = make_batch(dims, B * nb, seed=61, sparse=True)
+    chain = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    assert chain.step_launches == 2
+    monkeypatch.setenv("GNN_MLP_CHAIN", "0")
+    three = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    monkeypatch.delenv("GNN_MLP_CHAIN")
+    assert three.step_launches == 3
+    stepwise = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    hinted = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    ref = oracle_mod.OracleNet(dims, inner_act=inner)
+    ref.set_alloc_per_sample(0)
+    for net in (chain, three, stepwise, hinted):
+        net.upload_dataset(X, Y)
+    chain.train_range(0, B, n, 0.0125, 0.9)                     # one chain of n steps
+    three.train_range(0, B, n, 0.0125, 0.9)
+    for s in range(n):                                          # n chains of one step: forward-only launch each time
+        stepwise.gradient_step_range((s % nb) * B, B, 0.0125, 0.9)
+        if s % 3 != 2:                                          # hints on most steps, a wrong one in between
+            hinted.hint_next_range(((s + 1) % nb) * B if s % 3 == 0 else ((s + 2) % nb) * B, B)
+        hinted.gradient_step_range((s % nb) * B, B, 0.0125, 0.9)
+        ref.gradient_step(X[(s % nb) * B:(s % nb + 1) * B], Y[(s % nb) * B:(s % nb + 1) * B], 0.0125, 0.9)
+    w = chain.get_weights()
+    assert np.array_equal(w, stepwise.get_weights()) and np.array_equal(w, hinted.get_weights())
+    assert np.array_equal(chain.get_momentum(), stepwise.get_momentum())
+    assert np.abs(w - three.get_weights()).max() <= 2e-6
+    assert np.abs(w - ref.get_weights()).max() <= n * W_ATOL
+    # the split path (gradient buffer, flat or tile update) on the same chain, with hints: equal to the fused update bitwise
+    # (one spelling of the update arithmetic in every kernel)
+    split = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    split.upload_dataset(X, Y)
+    for s in range(n):
+        if s % 2 == 0:
+            split.hint_next_range(((s + 1) % nb) * B, B)        # tile update + next slabs; odd steps: flat update kernel
+        split.compute_gradient_range((s % nb) * B, B)
+        split.apply_update(B, 0.0125, 0.9)
+    assert np.array_equal(w, split.get_weights())
+    # inference after training is the three-launch forward (fwd_first): same weights, oracle tolerance
+    p, pr = chain.propagate(X[:B]), ref.propagate(X[:B])
+    assert np.abs(p - pr).max() <= 5e-4
 
 
 def test_config5_hipgraph_captured_step_equals_eager(gnn, monkeypatch):
