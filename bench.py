@@ -417,12 +417,12 @@ def worker(args, argv):
                     "tflops": round(flop / (us * 1e-6) / 1e12, 3), "gbs": round(nbytes / (us * 1e-6) / 1e9, 1),
                     "mfma_frac": round(flop / (us * 1e-6) / 1e12 / mfma_peak, 4),
                     "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                    "share_of_step": round(us / step_us, 3),
+                    "share_of_step": round(us * n / (step_us * nt), 3),
                     "traffic": None if is_dp or bf16 else pmc_traffic(pmc_key[k])}
         if kernels:
             # roofline kernel = the one with the largest share of the step's time.  Which roof: its
             # arithmetic intensity against the ridge of this dtype (peak FLOP/s / 8 TB/s).
-            dom = max(kernels, key=lambda k: kernels[k][0])
+            dom = max(kernels, key=lambda k: kernels[k][0] * kernels[k][1])   # total time in the timed pass = avg x launches
             e = entry(dom)
             ai = e["flop"] / e["algorithmic_bytes"]
             ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)

@@ -46,6 +46,11 @@ struct Mid4Plan {
     int st_rpt[MAX_LAYERS], st_trips[MAX_LAYERS], st_begin[MAX_LAYERS], st_total; // slabs per layer / first slot / all
     unsigned inv_n4[MAX_LAYERS];    // ceil(2^22 / (ld[l]/4)): epilogue thread -> row = (t * inv) >> 22 (t < 1024, ld <= 1024)
     unsigned st_inv_c4[MAX_LAYERS]; // ceil(2^22 / c4): thread -> slab row = (t * inv) >> 22 (exact for t < 1024, c4 <= 256)
+    // first-layer K slabs (SLABS kernels): ns slabs of 64 input neurons; the 4 x ld[1]/4 float4 elements of the four
+    // A_1 rows are each summed by sgrp threads (thread t -> element t % ld[1], group t / ld[1]; group g takes the
+    // slabs g, g + sgrp, ..), the group sums meet in the scratch area: every thread has loads in flight
+    int ns, sgrp;
+    unsigned inv_e;          // ceil(2^22 / ld[1])
     int lds_floats;          // total dynamic LDS, floats
     bool ok;
 };
@@ -104,6 +109,12 @@ __host__ __device__ constexpr Mid4Plan make_mid4_plan(const int *dims, int L) {
         m.ks_bwd[l] = ks;
         if (ks * 4 * gw > scratch) scratch = ks * 4 * gw;
     }
+    m.ns = (m.ld[0] + 63) / 64;
+    m.inv_e = ((1u << 22) + m.ld[1] - 1) / m.ld[1];
+    m.sgrp = mid4_min(mid4_min(m.ns, 1024 / m.ld[1]), 4);
+    if (m.sgrp < 1) m.sgrp = 1;
+    while (m.sgrp > 1 && m.sgrp * 4 * m.ld[1] > budget) m.sgrp--;
+    if (m.sgrp > 1 && m.sgrp * 4 * m.ld[1] > scratch) scratch = m.sgrp * 4 * m.ld[1];
     m.lds_floats = off + scratch + 64;
     m.ok = true;
     return m;
@@ -268,33 +279,45 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     const int a1_r = t / q1, a1_q = t - a1_r * q1, y_e = NT_ - 1 - t, y_r = y_e / qy, y_q = y_e - y_r * qy;
     // (lanes without an element re-read element 0 and never store it)
     f32x4 a1v = {0.f, 0.f, 0.f, 0.f};
-    constexpr int NSV = NS > 0 ? NS : (NS < 0 ? MID4_MAX_SLABS : 1);
-    f32x4 zs[NSV];
     const int ns = NS > 0 ? NS : (NS < 0 ? p.n_slabs : 0); // block-uniform
+    const int sg = (NS != 0) ? m.sgrp : 1;                 // threads per A_1 element (slab groups)
+    constexpr int NSV = NS > 0 ? NS : (NS < 0 ? MID4_MAX_SLABS : 1); // most slabs one thread may have to take (sg = 1)
+    f32x4 zs[NSV];
+    // thread -> (element se of the 4 x ld[1]/4 float4s, slab group sgi); with sg = 1 this is (t, 0) for t < 4*q1
+    const int sgi = (NS != 0 && sg > 1) ? (NSLOT > 0 ? t / m.ld[1] : (int)(((unsigned)t * m.inv_e) >> 22)) : 0;
+    const int se = t - sgi * m.ld[1];
+    const bool s_on = (sg > 1) ? sgi < sg : a1_on;
+    const int s_r = (sg > 1) ? se / q1 : a1_r, s_q = (sg > 1) ? se - s_r * q1 : a1_q;
     if constexpr (NS == 0) {
         a1v = *reinterpret_cast<const f32x4 *>(p.act[1] + (a1_on ? (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4 : (size_t)0));
     } else {
-        const float *zp = p.slabs + (a1_on ? (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4 : (size_t)0);
+        const float *zp = p.slabs + (s_on ? (size_t)(row0 + s_r) * m.ld[1] + s_q * 4 : (size_t)0);
         const size_t sstride = (size_t)p.slab_rows * m.ld[1];
 #pragma unroll
-        for (int s_ = 0; s_ < NSV; s_++) {
-            zs[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (s_ < ns) zs[s_] = *reinterpret_cast<const f32x4 *>(zp + s_ * sstride);
+        for (int i = 0; i < NSV; i++) {
+            const int s_ = sgi + i * sg;
+            zs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (s_ < ns) zs[i] = *reinterpret_cast<const f32x4 *>(zp + (s_on ? s_ * sstride : (size_t)0));
         }
     }
-    // slabs in slab order, then f; rows past the batch and columns past d_1 are zeros (f(0) != 0 for the sigmoid)
+    // this thread's slabs in ascending order; with one thread per element that is the whole sum: then f;
+    // rows past the batch and columns past d_1 are zeros (f(0) != 0 for the sigmoid)
     auto finish_a1 = [&]() {
         if constexpr (NS != 0) {
 #pragma unroll
-            for (int s_ = 0; s_ < NSV; s_++) asm volatile("" : "+v"(zs[s_])); // every slab load issued before the first add waits
+            for (int i = 0; i < NSV; i++) asm volatile("" : "+v"(zs[i])); // every slab load issued before the first add waits
             f32x4 z = zs[0];
 #pragma unroll
-            for (int s_ = 1; s_ < NSV; s_++)
-                if (s_ < ns) z += zs[s_];
-            const bool lrow = row0 + a1_r < p.B;
+            for (int i = 1; i < NSV; i++)
+                if (sgi + i * sg < ns) z += zs[i];
+            if (sg > 1) { // group sum to the scratch area; the element's first thread finishes after the barrier
+                if (s_on) *reinterpret_cast<f32x4 *>(smem + m.off_scratch + (sgi * m.ld[1] + se) * 4) = z;
+            } else {
+                const bool lrow = row0 + a1_r < p.B;
 #pragma unroll
-            for (int j = 0; j < 4; j++) a1v[j] = (lrow && a1_q * 4 + j < m.d[1]) ? act_fn(ACT, z[j]) : 0.f;
-            if (a1_on) *reinterpret_cast<f32x4 *>(p.act[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) = a1v; // the gradient kernel reads A_1
+                for (int j = 0; j < 4; j++) a1v[j] = (lrow && a1_q * 4 + j < m.d[1]) ? act_fn(ACT, z[j]) : 0.f;
+                if (a1_on) *reinterpret_cast<f32x4 *>(p.act[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) = a1v; // the gradient kernel reads A_1
+            }
         }
     };
     size_t y_row = (size_t)(row0 + y_r);
@@ -338,7 +361,7 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
 #pragma unroll
             for (int i = 0; i < NSLOT; i++) asm volatile("" : "+v"(v[i]));
             finish_a1();
-            if (a1_on) *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
+            if (a1_on && sg == 1) *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
             if (y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv;
 #pragma unroll
             for (int j = 1; j < MAX_LAYERS - 1; j++) {
@@ -384,7 +407,7 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                         if (j == 1 && tb == 0) { // the first weight loads are in flight: now the rows
                             asm volatile("" : "+v"(a1v), "+v"(yv));
                             finish_a1();
-                            if (a1_on) *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
+                            if (a1_on && sg == 1) *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
                             if (y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv;
                         }
 #pragma unroll
@@ -400,6 +423,19 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
         }
     }
     __syncthreads();
+    if (NS != 0 && sg > 1) {
+        // group sums in group order (fixed), then f: the first thread of every element
+        if (a1_on) {
+            f32x4 z = *reinterpret_cast<const f32x4 *>(smem + m.off_scratch + t * 4);
+            for (int g = 1; g < sg; g++) z += *reinterpret_cast<const f32x4 *>(smem + m.off_scratch + (g * m.ld[1] + t) * 4);
+            const bool lrow = row0 + a1_r < p.B;
+#pragma unroll
+            for (int j = 0; j < 4; j++) a1v[j] = (lrow && a1_q * 4 + j < m.d[1]) ? act_fn(ACT, z[j]) : 0.f;
+            *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
+            *reinterpret_cast<f32x4 *>(p.act[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) = a1v; // the gradient kernel reads A_1
+        }
+        __syncthreads();
+    }
     GNN_STAMP4(1);
 
     constexpr bool IS_STATIC = NSLOT > 0;

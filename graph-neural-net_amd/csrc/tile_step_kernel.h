@@ -26,7 +26,9 @@
 //
 // All contractions on v_mfma_f32_16x16x4_f32 (exact f32).  8 waves:
 //   gradient: wave -> (m tile of 16 = wave & 3, half of every 128-row K chunk = wave >> 2)
-//   forward : wave -> 16 batch rows of every 128-row chunk; K = the tile's 64 input neurons
+//   forward : wave -> 16 batch rows of every 128-row chunk; K = the tile's 64 input neurons; A_0' rows go
+//             straight to registers in fragment form and the product is taken transposed, so that the
+//             slab is stored 16 B per lane from the accumulators (no LDS image, one barrier in all)
 #pragma once
 #include "fused_kernels.h"
 
@@ -47,20 +49,29 @@ struct TileStepParams {
     int next_rows, next_K;       // live / padded rows of the next batch
     float *slabs;                // [n slabs][slab_rows][ldz]
     int slab_rows, ldz;
+    unsigned long long *stamps;  // STAMP builds only (tools/tile_probe.hip): 16 slots per block
 };
 
-template <int GSRC, int GDST, bool FWD>
+#define GNN_TS_STAMP(i)                                                                                  \
+    do {                                                                                                 \
+        if (STAMP && threadIdx.x == 0) p.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#define GNN_TS_STAMP_REAL(i)                                                                             \
+    do {                                                                                                 \
+        if (STAMP && threadIdx.x == 0) p.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+
+template <int GSRC, int GDST, bool FWD, bool STAMP = false>
 __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p) {
     constexpr int LDA = TS_TM + 16;  // gradient A image [k][m]: row stride = 16 (mod 32) floats
     constexpr int LDD = TS_TN;       // delta image [k][n]: 16 floats (lanes 16-31 land on banks 16-31)
-    constexpr int LDN = TS_TM + 8;   // forward A' image [b][m]: the b128 reads of a 16-lane group (rows fr, k offsets 4*fq) hit 16 different 16-B slots
     constexpr int LDW = TS_TN + 4;   // weight tile / partial tiles [m][n]
-    constexpr int A_FLOATS = TS_KC * (LDA > LDN ? LDA : LDN);
+    constexpr int A_FLOATS = TS_KC * LDA;
     static_assert(2 * TS_TM * LDW <= A_FLOATS, "the two partial G tiles reuse the A image");
-    __shared__ __attribute__((aligned(16))) float sA[A_FLOATS];         // A chunk; then the two K halves of G; then the A' chunks
-    __shared__ __attribute__((aligned(16))) float sD[TS_KC * LDW];       // delta chunk [128][16]; later the slab tile [128][20]
+    __shared__ __attribute__((aligned(16))) float sA[A_FLOATS];         // A chunk; then the two K halves of G
+    __shared__ __attribute__((aligned(16))) float sD[TS_KC * LDD];       // delta chunk [128][16]
     __shared__ __attribute__((aligned(16))) float sW[TS_TM * LDW];       // the tile's (new) weights
-    float *sC = sA;                                                      // (55 KB in all: two workgroups per CU)
+    float *sC = sA;                                                      // (53 KB in all: two workgroups per CU)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -80,6 +91,8 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     const bool e_ok = t < 256 && (m0 + er < L.M);
     const size_t e_off = (size_t)(m0 + er) * L.ldd + n0 + eq * 4;
 
+    GNN_TS_STAMP(0);
+    GNN_TS_STAMP_REAL(8);
     // ---- everything this block reads first, all loads in flight together ------------------------
     // gradient operands of the first K chunk
     float4 va[4], vd;
@@ -108,20 +121,24 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
         if (GDST == 2) v_old = *reinterpret_cast<const float4 *>(L.V + e_off);
         if (GSRC == 2) g_in = *reinterpret_cast<const float4 *>(L.G + e_off);
     }
-    // first chunk of the next batch's rows (held in registers until the A image is free)
-    float4 vn[4];
+    // the next batch's rows, already in MFMA fragment form: wave -> 16 batch rows of a 128-row chunk, lane
+    // (fr, fq) -> row fr, inputs 16c + 4fq .. +3 of the tile (c = 0..3).  Straight to registers: A_0' is
+    // k-contiguous, no wave shares another's rows, and the product below needs no LDS image of it.
+    f32x4 vn[4];
     auto load_next = [&](int b0) {
+        const int b = b0 + wave * 16 + fr;
+        const bool live = b < p.next_rows;
+        const size_t row = live ? (p.next_idx ? (size_t)p.next_idx[b] : (size_t)b) : 0;
+        const float *src = p.An + row * p.ldan + m0 + 4 * fq;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = t + i * TS_THREADS, b = idx >> 4, q = idx & 15;
-            vn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b0 + b < p.next_rows && m0 + q * 4 < L.M) {
-                const size_t row = p.next_idx ? (size_t)p.next_idx[b0 + b] : (size_t)(b0 + b);
-                vn[i] = *reinterpret_cast<const float4 *>(p.An + row * p.ldan + m0 + q * 4);
-            }
+        for (int c = 0; c < 4; c++) {
+            vn[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (live && m0 + c * 16 + 4 * fq < L.M) vn[c] = *reinterpret_cast<const f32x4 *>(src + c * 16);
         }
     };
-    if (fwd) load_next(0);
+    // (requested behind the gradient operands, below: it is needed ~2 500 cycles later, and in front of them it
+    //  delayed the first barrier by the time its 32 KB take to cross the CU's load path)
+    if (fwd && GSRC != 1) load_next(0);
 
     // ---- gradient tile: G[m][n] = sum_k A[k][m] D[k][n] ------------------------------------------
     float4 g = g_in;
@@ -154,6 +171,10 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
             }
             *reinterpret_cast<float4 *>(&sD[(t >> 2) * LDD + (t & 3) * 4]) = vd;
             __syncthreads();
+            if (k0 == 0) {
+                GNN_TS_STAMP(1);
+                if (fwd) load_next(0); // lands under the gradient MFMAs and the update
+            }
             const float *ap = &sA[fq * LDA + mt * 16 + fr];
             const float *dp = &sD[fq * LDD + fr];
             const int kbeg = kh * (kc >> 1), kend = kbeg + (kc >> 1); // kc/2 is a multiple of 8
@@ -172,6 +193,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * LDA], dp[kk * LDD], acc0, 0, 0, 0);
         }
         const f32x4 acc = acc0 + acc1;
+        GNN_TS_STAMP(2);
         __syncthreads(); // every wave has finished reading the A image
 #pragma unroll
         for (int r = 0; r < 4; r++) sC[(kh * TS_TM + mt * 16 + fq * 4 + r) * LDW + fr] = acc[r];
@@ -199,53 +221,42 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
             *reinterpret_cast<float4 *>(L.V + e_off) = adj;
         }
     }
-    if (!fwd) return;
+    GNN_TS_STAMP(3);
+    if (!fwd) { GNN_TS_STAMP_REAL(9); return; }
 
     // ---- the next batch's first-layer sums over this tile's 64 input neurons ---------------------
+    // Computed TRANSPOSED, Zp^T[n][b] = sum_m W[m][n] A'[b][m]: the accumulator then holds four
+    // consecutive n of one batch row per lane -- a 16-B store each, no trip through LDS.
+    // MFMA j of chunk c: slot q holds k = 16c + 4q + j on both operands.
     if (t < 256) *reinterpret_cast<float4 *>(&sW[er * LDW + eq * 4]) = e_ok ? w_new : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    GNN_TS_STAMP(4);
     float *slab = p.slabs + (size_t)tm * p.slab_rows * p.ldz;
+    const float *wcol = &sW[(4 * fq) * LDW + fr];
+    float wv[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) wv[c][j] = wcol[(c * 16 + j) * LDW];
     for (int b0 = 0; b0 < p.next_K; b0 += TS_KC) {
         if (b0) load_next(b0);
-        __syncthreads(); // the A image (or the previous chunk's A' image and slab tile) is free; sW is written
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = t + i * TS_THREADS, b = idx >> 4, q = idx & 15;
-            *reinterpret_cast<float4 *>(&sA[b * LDN + q * 4]) = vn[i];
-        }
-        __syncthreads();
-        // wave -> 16 batch rows; A' is k-contiguous: one b128 per 16 k (slot q of MFMA j holds k = 16c + 4q + j)
-        if (b0 + wave * 16 < p.next_K) {
+        if (b0 + wave * 16 < p.next_K) { // wave-uniform
             f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-            const float *arow = &sA[(wave * 16 + fr) * LDN + 4 * fq];
-            const float *wcol = &sW[(4 * fq) * LDW + fr];
-            f32x4 a[4];
-            float b[4][4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                a[c] = *reinterpret_cast<const f32x4 *>(arow + c * 16);
-#pragma unroll
-                for (int j = 0; j < 4; j++) b[c][j] = wcol[(c * 16 + j) * LDW];
-            }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    if (c & 1) z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], z1, 0, 0, 0);
-                    else z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], z0, 0, 0, 0);
+                    if (c & 1) z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][j], vn[c][j], z1, 0, 0, 0);
+                    else z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][j], vn[c][j], z0, 0, 0, 0);
                 }
             }
-            const f32x4 z = z0 + z1;
-#pragma unroll
-            for (int r = 0; r < 4; r++) sD[(wave * 16 + fq * 4 + r) * LDW + fr] = z[r];
-        }
-        __syncthreads();
-        {   // one 16-B store per thread: row b = t / 4, columns 4*(t%4)..
-            const int b = t >> 2, q = t & 3;
-            if (b0 + b < p.next_K)
-                *reinterpret_cast<float4 *>(slab + (size_t)(b0 + b) * p.ldz + n0 + q * 4) =
-                    *reinterpret_cast<const float4 *>(&sD[b * LDW + q * 4]);
+            const f32x4 z = z0 + z1; // rows n = 4*fq + r, column b = fr
+            GNN_TS_STAMP(5);
+            *reinterpret_cast<f32x4 *>(slab + (size_t)(b0 + wave * 16 + fr) * p.ldz + n0 + 4 * fq) = z;
         }
     }
+    GNN_TS_STAMP(6);
+    GNN_TS_STAMP_REAL(9);
 }
 
 } // namespace gnn

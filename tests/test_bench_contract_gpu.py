@@ -42,7 +42,7 @@ def check(line, n_gpus=1, dtype="f32", shared_gpu=False):
     assert r["bound"] in ("hbm", "mfma") and (0 if shared_gpu else 1e-4) <= r["frac"] < 1 and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # the roofline kernel is the one with the largest share of the step
-    assert all(r["avg_launch_us"] >= o["avg_us"] for o in r["other"].values())
+    assert all(r["avg_launch_us"] * r["launches"] >= o["avg_us"] * o["launches"] for o in r["other"].values())
 
 
 def test_bench_line_single_process():

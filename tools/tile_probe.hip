@@ -1,0 +1,71 @@
+// tile_probe.hip -- development harness (not shipped): tile_step_kernel on the 784-300-100-10 / B = 128
+// shapes with random data: HIP-event time per call of every mode and in-kernel phase stamps (STAMP build).
+#include "../graph-neural-net_amd/csrc/tile_step_kernel.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace gnn;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+int main(int argc, char **argv) {
+    const int L = 4, dims[4] = {784, 300, 100, 10};
+    const int B = argc > 1 ? atoi(argv[1]) : 128;
+    int ld[4]; for (int i = 0; i < L; i++) ld[i] = pad_up(dims[i]);
+    const int Bp = pad_up(B);
+    size_t woff[3], np = 0; for (int l = 0; l < 3; l++) { woff[l] = np; np += (size_t)ld[l] * ld[l + 1]; }
+    float *W, *V, *G, *act[4], *delta[4], *slabs, *An; unsigned long long *stamps;
+    CK(hipMalloc(&W, np * 4)); CK(hipMalloc(&V, np * 4)); CK(hipMalloc(&G, np * 4));
+    std::vector<float> hw(np, 0.f);
+    for (int l = 0; l < 3; l++) for (int i = 0; i < dims[l]; i++) for (int j = 0; j < dims[l + 1]; j++)
+        hw[woff[l] + (size_t)i * ld[l + 1] + j] = (rand() / (float)RAND_MAX - 0.5f) * 0.2f;
+    CK(hipMemcpy(W, hw.data(), np * 4, hipMemcpyHostToDevice)); CK(hipMemset(V, 0, np * 4)); CK(hipMemset(G, 0, np * 4));
+    for (int l = 0; l < L; l++) {
+        std::vector<float> h((size_t)Bp * ld[l], 0.f);
+        for (int b = 0; b < B; b++) for (int i = 0; i < dims[l]; i++) h[(size_t)b * ld[l] + i] = rand() / (float)RAND_MAX - 0.3f;
+        CK(hipMalloc(&act[l], h.size() * 4)); CK(hipMemcpy(act[l], h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        for (auto &x : h) x *= 1e-3f;
+        CK(hipMalloc(&delta[l], h.size() * 4)); CK(hipMemcpy(delta[l], h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    }
+    CK(hipMalloc(&An, (size_t)Bp * ld[0] * 4)); CK(hipMemcpy(An, act[0], (size_t)Bp * ld[0] * 4, hipMemcpyDeviceToDevice));
+    const int ns = (ld[0] + TS_TM - 1) / TS_TM;
+    CK(hipMalloc(&slabs, (size_t)ns * Bp * ld[1] * 4));
+    CK(hipMalloc(&stamps, 4096 * 16 * 8)); CK(hipMemset(stamps, 0, 4096 * 16 * 8));
+    TileStepParams t{}; t.n_layers = 3; int tiles = 0, tiles0 = 0;
+    for (int l = 0; l < 3; l++) { GradLayer &gl = t.layer[l]; gl.A = act[l]; gl.lda = ld[l]; gl.D = delta[l + 1]; gl.ldd = ld[l + 1];
+        gl.W = W + woff[l]; gl.V = V + woff[l]; gl.G = G + woff[l]; gl.M = ld[l]; gl.N = ld[l + 1];
+        gl.tiling = make_xcd_tiling((gl.M + TS_TM - 1) / TS_TM, gl.N / TS_TN); gl.block_begin = tiles; tiles += gl.tiling.blocks(); if (!l) tiles0 = tiles; }
+    t.K = Bp; t.k_true = B; t.step_over_b = 1e-4f; t.momentum = 0.9f;
+    t.An = An; t.ldan = ld[0]; t.next_rows = B; t.next_K = Bp; t.slabs = slabs; t.slab_rows = Bp; t.ldz = ld[1]; t.stamps = stamps;
+    printf("tiles: %d (layer 0: %d), %d slabs\n", tiles, tiles0, ns);
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time_it = [&](const char *name, int n, auto fn) {
+        for (int i = 0; i < 20; i++) fn();
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < n; i++) fn();
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-44s %8.2f us per call\n", name, ms * 1000.f / n);
+    };
+    time_it("tile_step<grad, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<grad, update>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, false>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<grad, store G>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 1, false>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<G, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<2, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<fwd only> (layer 0 tiles)", 500, [&]() { TileStepParams u = t; u.n_layers = 1; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
+    CK(hipMemsetAsync(stamps, 0, 4096 * 16 * 8, s));
+    hipLaunchKernelGGL((tile_step_kernel<1, 2, true, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t);
+    CK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> hs((size_t)tiles * 16);
+    CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0, s1 = 0;
+    for (int w = 0; w < tiles; w++) { if (!hs[w * 16 + 8]) continue; t0 = std::min(t0, hs[w * 16 + 8]); t1 = std::max(t1, hs[w * 16 + 9]); s1 = std::max(s1, hs[w * 16 + 8]); }
+    printf("first block start -> last block end %.2f us; last block starts %.2f us after the first\n", (t1 - t0) / 100.0, (s1 - t0) / 100.0);
+    for (int w : {0, 1, 100, 200, 246, 250, 280}) {
+        if (w >= tiles || !hs[w * 16 + 8]) continue;
+        const unsigned long long *q = &hs[w * 16];
+        printf("wg%-3d start+%.2f us: loads->LDS %llu | grad mfma %llu | reduce+update %llu | sW barrier %llu | fwd mfma %llu | store %llu | total %llu cycles (%.2f us)\n", w,
+               (q[8] - t0) / 100.0, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] ? q[4] - q[3] : 0, q[5] ? q[5] - q[4] : 0, q[6] ? q[6] - q[5] : 0, (q[6] ? q[6] : q[3]) - q[0], (q[9] - q[8]) / 100.0);
+    }
+    return 0;
+}
