@@ -1,10 +1,26 @@
-// gemm_bf16.h -- GNN_DTYPE_BF16: the same three GEMM forms as kernels.h with bf16 OPERANDS and
+// gemm_bf16.h -- GNN_DTYPE_BF16: the three GEMM forms of kernels.h with bf16 OPERANDS IN HBM and
 // f32 accumulation on v_mfma_f32_16x16x32_bf16 (K = 32 per instruction, 16x the f32 MFMA rate).
-// Master weights, momentum, activations and deltas stay f32 in HBM; a tile is rounded to bf16
-// (v_cvt_pk_bf16_f32, round-to-nearest-even) while it is staged into LDS, so no shadow copies
-// exist and the epilogues (activation, f', fused momentum update on the f32 masters) are the
-// f32 ones.  LDS image: [row][k] bf16, k contiguous, row stride 72 (144 B = 9 x 16 B, odd): a
-// fragment (8 consecutive k of one row) is one ds_read_b128 and 16 lanes hit 16 different slots.
+//
+// What lives where (bf16 mode):
+//   W, V (momentum), G      f32 masters, as in f32 mode (the update is SCE:333-339 in f32)
+//   Wb                      bf16 shadow of W, same padded [in][out] layout, rewritten by whatever updates W
+//   act[l] / actb[l]        f(z_l) in f32 (f' is taken from it, host exports) and its bf16 rounding (GEMM operand)
+//   delta[l] / deltab[l]    dE/dz_l in f32 and bf16
+// Every producer rounds ONCE (v_cvt_pk_bf16_f32, round-to-nearest-even) in its epilogue, so a GEMM
+// moves half the operand bytes and converts nothing.  Arithmetic contract = tests/np_oracle.py *_bf16:
+// every GEMM operand rounded to bf16, products exact, f32 accumulation.
+//
+// All three products read their operands in the NATURAL layouts (no transposed copies in HBM):
+//   forward   Z  = A . W        A [B][d_in] k-contiguous,   W [d_in][d_out] k-major
+//   backward  D' = D . W^T      D [B][d_out] k-contiguous,  W as stored is k-contiguous for this product
+//   gradient  G  = A^T . D      both operands k-major ([B][d] with k = batch row)
+// A k-contiguous tile is staged as [row][k] (row stride 72 bf16 = 144 B = 36 banks: ds_read_b64 of 16 rows x
+// 2 k-groups is conflict-free); a k-major tile is staged AS IT IS, [k][n] with a row stride of 32*odd bytes,
+// and read with ds_read_b64_tr_b16, the gfx950 transpose read (per 16 lanes: a 4 x 16 block, lane i gets
+// column i).  So that those reads are conflict-free the k values of one MFMA are dealt to the four 16-lane
+// groups as  element j < 4: k = 4g + j,  j >= 4: k = 16 + 4g + (j - 4)  -- any assignment of distinct k
+// to slots is a valid product as long as both operands use the same one; a 32-lane half then reads rows
+// 0..7 (16..23) of the block, eight rows x 32 B = all 64 banks once.
 #pragma once
 #include "kernels.h"
 
@@ -12,82 +28,104 @@ namespace gnn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct GemmBf16Params {
+    const __bf16 *A; int lda;
+    const __bf16 *B; int ldb;
+    float *C; int ldc;            // f32 result (may be null when only the bf16 copy is wanted)
+    __bf16 *Cb;                   // bf16 rounding of what C receives, same ld (may be null)
+    int M, N, K;                  // padded extents (multiples of 16)
+    int m_true, n_true;           // logical extents (zeros are stored beyond them)
+    const float *aux; int ldaux;  // EPI_DACT: a = f(z) of this layer (f32)
+    float *W; float *V; __bf16 *Wb; // EPI_SGD: masters and the bf16 shadow (same ld as C)
+    float step_over_b, momentum;
+    int act;
+};
+
+__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// K depth of one staged tile.  A 4-wave workgroup keeps TWO tiles ahead in registers while it multiplies the
+// staged one (the loads of tile t+2 are issued before tile t is multiplied); with one workgroup per CU (grids
+// of 256..511 tiles) that is all the CU has in flight, and it must cover a memory round trip (~1 500 cycles
+// under load) at the CU's load rate: 2 x 32 KB for 64 x 64 tiles (BK 128), 2 x 32 KB for 128 x 128 (BK 64).
+// With ONE 16-KB tile ahead (BK 64) the 512-row products of 4096-2048-2048-1024 ran at 11 B/clk/CU.
+template <int BM> struct GemmBf16Depth { static constexpr int BK = BM >= 128 ? 64 : BM >= 64 ? 128 : 256; };
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+constexpr size_t gemm_bf16_lds_bytes() {
+    constexpr int BK = GemmBf16Depth<BM>::BK, LDK = BK + 8;
+    constexpr int LDTA = BM + ((BM / 16) % 2 == 0 ? 16 : 0), LDTB = BN + ((BN / 16) % 2 == 0 ? 16 : 0);
+    return sizeof(__bf16) * ((A_KC ? BM * LDK : BK * LDTA) + (B_KC ? BN * LDK : BK * LDTB));
+}
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
-    constexpr int BK = 64, LDK = BK + 8;
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
+    constexpr int BK = GemmBf16Depth<BM>::BK;
     constexpr int TM = BM / 32, TN = BN / 32; // 16x16 MFMA tiles per wave (waves are 2 x 2)
-    __shared__ __attribute__((aligned(16))) __bf16 As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[BN * LDK];
+    constexpr int LDK = BK + 8;               // k-contiguous image: row stride = 4 banks (mod 64): 16 rows x 2 k-groups of a ds_read_b64 hit 64 banks once
+    // k-major image: row stride 32*odd bytes (BM = 128: 288 B, 64: 160 B, 32: 96 B)
+    constexpr int LDTA = BM + ((BM / 16) % 2 == 0 ? 16 : 0), LDTB = BN + ((BN / 16) % 2 == 0 ? 16 : 0);
+    constexpr int A_ELEMS = A_KC ? BM * LDK : BK * LDTA, B_ELEMS = B_KC ? BN * LDK : BK * LDTB;
+    extern __shared__ __attribute__((aligned(16))) __bf16 gemm_bf16_smem[]; // up to 70 KB: dynamic (opt-in above 64 KB)
+    __bf16 *As = gemm_bf16_smem, *Bs = gemm_bf16_smem + A_ELEMS;
+    static_assert(sizeof(__bf16) * (A_ELEMS + B_ELEMS) == gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC>(), "LDS size");
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256; // float4 per thread per tile
-    float4 ra[NA], rb[NB];
+    constexpr int NA = BM * BK / 8 / 256, NB = BN * BK / 8 / 256; // 16-B chunks (8 bf16) per thread per tile
+    static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+    bf16x8 ra0[NA], rb0[NB], ra1[NA], rb1[NB]; // two register stages
 
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](int k0, bf16x8 (&ra)[NA], bf16x8 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int idx = t + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = t + i * 256;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (A_KC) {
-                const int m = idx % BM, kq = idx / BM;
-                if (m0 + m < p.M && k0 + kq * 4 < p.K)
-                    v = *reinterpret_cast<const float4 *>(p.A + (size_t)(m0 + m) * p.lda + k0 + kq * 4);
+                const int row = c / (BK / 8), kq = c % (BK / 8);
+                if (m0 + row < p.M && k0 + kq * 8 < p.K)
+                    v = *reinterpret_cast<const bf16x8 *>(p.A + (size_t)(m0 + row) * p.lda + k0 + kq * 8);
             } else {
-                const int k = idx / (BM / 4), mq = idx % (BM / 4);
-                if (k0 + k < p.K && m0 + mq * 4 < p.M)
-                    v = *reinterpret_cast<const float4 *>(p.A + (size_t)(k0 + k) * p.lda + m0 + mq * 4);
+                const int k = c / (BM / 8), mq = c % (BM / 8);
+                if (k0 + k < p.K && m0 + mq * 8 < p.M)
+                    v = *reinterpret_cast<const bf16x8 *>(p.A + (size_t)(k0 + k) * p.lda + m0 + mq * 8);
             }
             ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int idx = t + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = t + i * 256;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (B_KC) {
-                const int n = idx % BN, kq = idx / BN;
-                if (n0 + n < p.N && k0 + kq * 4 < p.K)
-                    v = *reinterpret_cast<const float4 *>(p.B + (size_t)(n0 + n) * p.ldb + k0 + kq * 4);
+                const int row = c / (BK / 8), kq = c % (BK / 8);
+                if (n0 + row < p.N && k0 + kq * 8 < p.K)
+                    v = *reinterpret_cast<const bf16x8 *>(p.B + (size_t)(n0 + row) * p.ldb + k0 + kq * 8);
             } else {
-                const int k = idx / (BN / 4), nq = idx % (BN / 4);
-                if (k0 + k < p.K && n0 + nq * 4 < p.N)
-                    v = *reinterpret_cast<const float4 *>(p.B + (size_t)(k0 + k) * p.ldb + n0 + nq * 4);
+                const int k = c / (BN / 8), nq = c % (BN / 8);
+                if (k0 + k < p.K && n0 + nq * 8 < p.N)
+                    v = *reinterpret_cast<const bf16x8 *>(p.B + (size_t)(k0 + k) * p.ldb + n0 + nq * 8);
             }
             rb[i] = v;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](const bf16x8 (&ra)[NA], const bf16x8 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int idx = t + i * 256;
-            if (A_KC) {
-                const int m = idx % BM, kq = idx / BM;
-                bf16x4 q = {(__bf16)ra[i].x, (__bf16)ra[i].y, (__bf16)ra[i].z, (__bf16)ra[i].w};
-                *reinterpret_cast<bf16x4 *>(&As[m * LDK + kq * 4]) = q;
-            } else { // 4 rows at one k: transposing 2-byte writes
-                const int k = idx / (BM / 4), mq = idx % (BM / 4);
-                As[(mq * 4 + 0) * LDK + k] = (__bf16)ra[i].x;
-                As[(mq * 4 + 1) * LDK + k] = (__bf16)ra[i].y;
-                As[(mq * 4 + 2) * LDK + k] = (__bf16)ra[i].z;
-                As[(mq * 4 + 3) * LDK + k] = (__bf16)ra[i].w;
-            }
+            const int c = t + i * 256;
+            if (A_KC) *reinterpret_cast<bf16x8 *>(&As[(c / (BK / 8)) * LDK + (c % (BK / 8)) * 8]) = ra[i];
+            else *reinterpret_cast<bf16x8 *>(&As[(c / (BM / 8)) * LDTA + (c % (BM / 8)) * 8]) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int idx = t + i * 256;
-            if (B_KC) {
-                const int n = idx % BN, kq = idx / BN;
-                bf16x4 q = {(__bf16)rb[i].x, (__bf16)rb[i].y, (__bf16)rb[i].z, (__bf16)rb[i].w};
-                *reinterpret_cast<bf16x4 *>(&Bs[n * LDK + kq * 4]) = q;
-            } else {
-                const int k = idx / (BN / 4), nq = idx % (BN / 4);
-                Bs[(nq * 4 + 0) * LDK + k] = (__bf16)rb[i].x;
-                Bs[(nq * 4 + 1) * LDK + k] = (__bf16)rb[i].y;
-                Bs[(nq * 4 + 2) * LDK + k] = (__bf16)rb[i].z;
-                Bs[(nq * 4 + 3) * LDK + k] = (__bf16)rb[i].w;
-            }
+            const int c = t + i * 256;
+            if (B_KC) *reinterpret_cast<bf16x8 *>(&Bs[(c / (BK / 8)) * LDK + (c % (BK / 8)) * 8]) = rb[i];
+            else *reinterpret_cast<bf16x8 *>(&Bs[(c / (BN / 8)) * LDTB + (c % (BN / 8)) * 8]) = rb[i];
         }
     };
 
@@ -97,63 +135,123 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int fr = lane & 15, fq = lane >> 4;
-    // operand maps of mfma_f32_16x16x32_bf16: lane l holds A[row l&15][8*(l>>4) + j] and
-    // B[8*(l>>4) + j][col l&15], j = 0..7
-    const __bf16 *ap = &As[(wm * (TM * 16) + fr) * LDK + fq * 8];
-    const __bf16 *bp = &Bs[(wn * (TN * 16) + fr) * LDK + fq * 8];
+    const int fr = lane & 15, fg = lane >> 4;
+    // fragment of MFMA tile `tile` (16 rows / columns starting at r0) for the 32-wide k block at kk:
+    //   element j < 4: k = kk + 4 fg + j ; j >= 4: k = kk + 16 + 4 fg + (j - 4)
+    auto frag_kc = [&](const __bf16 *img, int r0, int kk) {
+        const __bf16 *q = img + (r0 + fr) * LDK + kk + 4 * fg;
+        return join8(*reinterpret_cast<const s16x4 *>(q), *reinterpret_cast<const s16x4 *>(q + 16));
+    };
+    auto frag_tr = [&](const __bf16 *img, int ldt, int c0, int kk) {
+        // lane 4q + p of a 16-lane group addresses row q, columns 4p..4p+3 of the 4 x 16 block; it receives column (lane & 15)
+        const __bf16 *q = img + (kk + 4 * fg + (fr >> 2)) * ldt + c0 + 4 * (fr & 3);
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q + 16 * ldt));
+        return join8(lo, hi);
+    };
 
-    load_tiles(0);
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
-        store_tiles();
-        __syncthreads();
-        if (k0 + BK < p.K) load_tiles(k0 + BK);
+    auto multiply = [&](int k0) {
+        const int kmax = (p.K - k0 < BK) ? p.K - k0 : BK; // K is a multiple of 16; rows past it were staged as zeros
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 32) {
+            if (kk >= kmax) break;
             bf16x8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const bf16x8 *>(ap + i * 16 * LDK + kk);
+            for (int i = 0; i < TM; i++)
+                a[i] = A_KC ? frag_kc(As, wm * (TM * 16) + i * 16, kk) : frag_tr(As, LDTA, wm * (TM * 16) + i * 16, kk);
 #pragma unroll
-            for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const bf16x8 *>(bp + j * 16 * LDK + kk);
+            for (int j = 0; j < TN; j++)
+                b[j] = B_KC ? frag_kc(Bs, wn * (TN * 16) + j * 16, kk) : frag_tr(Bs, LDTB, wn * (TN * 16) + j * 16, kk);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+    };
+    load_tiles(0, ra0, rb0);
+    if (BK < p.K) load_tiles(BK, ra1, rb1);
+    for (int k0 = 0; k0 < p.K; k0 += 2 * BK) { // two tiles per trip so that the stages keep their names
+        store_tiles(ra0, rb0);
         __syncthreads();
+        if (k0 + 2 * BK < p.K) load_tiles(k0 + 2 * BK, ra0, rb0);
+        multiply(k0);
+        __syncthreads();
+        if (k0 + BK < p.K) {
+            store_tiles(ra1, rb1);
+            __syncthreads();
+            if (k0 + 3 * BK < p.K) load_tiles(k0 + 3 * BK, ra1, rb1);
+            multiply(k0 + BK);
+            __syncthreads();
+        }
     }
 
-    // epilogue (f32, identical to gemm_f32_kernel): col = lane&15, row = (lane>>4)*4 + reg
+    // ---- epilogue ------------------------------------------------------------------------------------
+    // The accumulator of a 16x16 MFMA tile has its column on the lane (lane & 15) and four rows in the registers:
+    // stored as it stands that is 4 B per lane (64-B segments; W, V, Wb of the update: five such accesses per
+    // element).  Each wave therefore turns one row of its MFMA tiles (16 rows x TN*16 columns) at a time through a
+    // private LDS area and handles it as 16-B pieces: lane -> (row, 4 consecutive columns), 256-B runs per row.
+    constexpr int EW = TN * 16, ELD = EW + 4, C4 = EW / 4, RPP = 64 / C4, PASSES = 16 / RPP; // float4s per row, rows per pass
+    float *est = reinterpret_cast<float *>(gemm_bf16_smem) + wave * (16 * ELD);
+    static_assert(4 * 16 * ELD * sizeof(float) <= gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC>(), "epilogue staging fits the operand images");
+    const int erow = lane / C4, ec4 = lane % C4;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
+        asm volatile("" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = n0 + wn * (TN * 16) + j * 16 + fr;
+        for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int m = m0 + wm * (TM * 16) + i * 16 + fq * 4 + r;
-                if (m < p.M && n < p.N) {
-                    const bool live = (m < p.m_true) && (n < p.n_true);
-                    const float v = acc[i][j][r];
-                    const size_t off = (size_t)m * p.ldc + n;
-                    if (EPI == EPI_STORE) {
-                        p.C[off] = live ? v : 0.f;
-                    } else if (EPI == EPI_ACT) {
-                        p.C[off] = live ? act_fn(p.act, v) : 0.f;
-                    } else if (EPI == EPI_DACT) {
-                        const float a = p.aux[(size_t)m * p.ldaux + n];
-                        p.C[off] = live ? v * act_prime_from_a(p.act, a) : 0.f;
-                    } else { // EPI_SGD on the f32 masters: ((step*G)/B) + (momentum*prev), SCE:333
-                        if (live) {
-                            const float adj = sgd_adj(p.step_over_b, v, p.momentum, p.V[off]);
-                            p.W[off] -= adj;
-                            p.V[off] = adj;
+            for (int r = 0; r < 4; r++) est[(fg * 4 + r) * ELD + j * 16 + fr] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier(); // one wave, LDS operations complete in order: a scheduling fence is enough
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
+            const int row = ps * RPP + erow;
+            const int m = m0 + wm * (TM * 16) + i * 16 + row;
+            const int n = n0 + wn * EW + ec4 * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(est + row * ELD + ec4 * 4);
+            if (m < p.M && n < p.N) { // N is a multiple of 16: the four columns are all inside or all outside
+                const size_t off = (size_t)m * p.ldc + n;
+                f32x4 out = {0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_SGD) { // on the f32 masters, SCE:333; the bf16 shadow follows the master
+                    f32x4 w = *reinterpret_cast<const f32x4 *>(p.W + off);
+                    f32x4 vv = *reinterpret_cast<const f32x4 *>(p.V + off);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (m < p.m_true && n + e < p.n_true) {
+                            const float adj = sgd_adj(p.step_over_b, v[e], p.momentum, vv[e]);
+                            w[e] -= adj;
+                            vv[e] = adj;
                         }
                     }
+                    *reinterpret_cast<f32x4 *>(p.W + off) = w;
+                    *reinterpret_cast<f32x4 *>(p.V + off) = vv;
+                    *reinterpret_cast<bf16x4 *>(p.Wb + off) = (bf16x4){(__bf16)w[0], (__bf16)w[1], (__bf16)w[2], (__bf16)w[3]};
+                } else {
+                    f32x4 aux = {0.f, 0.f, 0.f, 0.f};
+                    if (EPI == EPI_DACT) aux = *reinterpret_cast<const f32x4 *>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const bool live = (m < p.m_true) && (n + e < p.n_true);
+                        if (EPI == EPI_STORE) out[e] = live ? v[e] : 0.f;
+                        else if (EPI == EPI_ACT) out[e] = live ? act_fn(p.act, v[e]) : 0.f;
+                        else out[e] = live ? v[e] * act_prime_from_a(p.act, aux[e]) : 0.f;
+                    }
+                    if (p.C) *reinterpret_cast<f32x4 *>(p.C + off) = out;
+                    if (p.Cb) *reinterpret_cast<bf16x4 *>(p.Cb + off) = (bf16x4){(__bf16)out[0], (__bf16)out[1], (__bf16)out[2], (__bf16)out[3]};
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// f32 -> bf16 (RNE) over a flat buffer: the shadow of W after set_weights / init / load, dataset rows, ...
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float4 *__restrict__ src, bf16x4 *__restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = src[i];
+        dst[i] = (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
     }
 }
 

@@ -68,6 +68,10 @@ struct gnn_mlp {
     double *stage_x = nullptr, *stage_y = nullptr, *stage_out = nullptr;
 
     float *DX = nullptr, *DY = nullptr; // device-resident dataset (A_0 = f(x) and y)
+    // GNN_DTYPE_BF16 (gemm_bf16.h): bf16 roundings of every GEMM operand, written once by its producer
+    __bf16 *Wb = nullptr;               // shadow of W, same padded layout
+    std::vector<__bf16 *> actb, deltab; // actb[l] l = 0..L-2, deltab[l] l = 1..L-1
+    __bf16 *DXb = nullptr;              // dataset inputs
     int64_t dataset_n = 0;
 
     hipStream_t stream = nullptr, own_stream = nullptr;
@@ -212,10 +216,7 @@ template <class K, class P> void launch_timed(gnn_mlp *h, int cls, K kernel, dim
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
 void launch_gemm_t(gnn_mlp *h, int cls, const GemmParams &p) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-    if (h->dtype == GNN_DTYPE_BF16)
-        launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI>, grid, dim3(256), 0, p);
-    else
-        launch_timed(h, cls, gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>, grid, dim3(256), 0, p);
+    launch_timed(h, cls, gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>, grid, dim3(256), 0, p);
 }
 
 // tile edge: keep >= ~256 workgroups in flight where the problem allows it (256 CUs)
@@ -237,6 +238,95 @@ void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
     case 64: launch_gemm_t<64, 64, A_KC, B_KC, EPI>(h, cls, p); break;
     default: launch_gemm_t<32, 32, A_KC, B_KC, EPI>(h, cls, p); break;
     }
+}
+
+// bf16 operands (gemm_bf16.h): the same tile choice; 128x128 tiles only when they alone fill the chip
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+void launch_gemm_bf16_t(gnn_mlp *h, int cls, const GemmBf16Params &p) {
+    constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC>();
+    static bool opted_in = false; // more than 64 KB of dynamic LDS needs the opt-in, once per instantiation
+    if (!opted_in) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            if (h->launch_error == hipSuccess) h->launch_error = hipGetLastError();
+        }
+        opted_in = true;
+    }
+    launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI>, dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(256), lds, p);
+}
+template <bool A_KC, bool B_KC, int EPI>
+void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
+    // bytes per MAC fall with the tile edge and these kernels are bound by operand traffic per CU, so 64 x 64 tiles
+    // already from 128 tiles up (f32 wants 256): the 512 x 1024 logits of 4096-2048-2048-1024 took 13.5 us on 32 x 32 tiles
+    int tile = pick_tile(p.M, p.N);
+    if (tile == 32 && (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64) >= 128) tile = 64;
+    switch (tile) {
+    case 128: launch_gemm_bf16_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;
+    case 64: launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI>(h, cls, p); break;
+    default: launch_gemm_bf16_t<32, 32, A_KC, B_KC, EPI>(h, cls, p); break;
+    }
+}
+
+// ---- bf16 mode: forward / backward over the bf16 operand copies -------------------------------------
+void forward_bf16(gnn_mlp *h, const __bf16 *a0b, int B) {
+    const int B_pad = pad_up(B);
+    const __bf16 *in = a0b;
+    for (int l = 1; l < h->L; l++) {
+        GemmBf16Params p{};
+        p.A = in; p.lda = h->ld[l - 1];
+        p.B = h->Wb + h->w_off[l - 1]; p.ldb = h->ld[l];
+        p.M = B_pad; p.N = h->ld[l]; p.K = h->ld[l - 1];
+        p.m_true = B; p.n_true = h->dims[l];
+        p.act = h->inner_act;
+        p.ldc = h->ld[l];
+        if (l < h->L - 1) {
+            p.C = h->act[l]; p.Cb = h->actb[l];
+            launch_gemm_bf16<true, false, EPI_ACT>(h, l == 1 ? GNN_K_FWD_GEMM0 : -1, p);
+            in = h->actb[l];
+        } else {
+            p.C = h->logits; p.Cb = nullptr;
+            launch_gemm_bf16<true, false, EPI_STORE>(h, l == 1 ? GNN_K_FWD_GEMM0 : -1, p);
+        }
+    }
+}
+
+void backward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool fused_update, float step_over_b, float momentum) {
+    const int B_pad = pad_up(B);
+    for (int l = h->L - 2; l >= 0; l--) {
+        if (l >= 1) { // delta_l = (delta_{l+1} . W_l^T) * f'(z_l)   -- before W_l is touched
+            GemmBf16Params p{};
+            p.A = h->deltab[l + 1]; p.lda = h->ld[l + 1];
+            p.B = h->Wb + h->w_off[l]; p.ldb = h->ld[l + 1];
+            p.C = h->delta[l]; p.Cb = h->deltab[l]; p.ldc = h->ld[l];
+            p.M = B_pad; p.N = h->ld[l]; p.K = h->ld[l + 1];
+            p.m_true = B; p.n_true = h->dims[l];
+            p.aux = h->act[l]; p.ldaux = h->ld[l];
+            p.act = h->inner_act;
+            launch_gemm_bf16<true, true, EPI_DACT>(h, -1, p);
+        }
+        GemmBf16Params g{}; // G_l = A_l^T . delta_{l+1}
+        g.A = (l == 0) ? a0b : h->actb[l]; g.lda = h->ld[l];
+        g.B = h->deltab[l + 1]; g.ldb = h->ld[l + 1];
+        g.ldc = h->ld[l + 1];
+        g.M = h->ld[l]; g.N = h->ld[l + 1]; g.K = B_pad;
+        g.m_true = h->dims[l]; g.n_true = h->dims[l + 1];
+        const int cls = (l == 0) ? GNN_K_GRAD_GEMM0 : -1;
+        if (fused_update) {
+            g.W = h->W + h->w_off[l]; g.V = h->V + h->w_off[l]; g.Wb = h->Wb + h->w_off[l];
+            g.step_over_b = step_over_b; g.momentum = momentum;
+            launch_gemm_bf16<false, false, EPI_SGD>(h, cls, g);
+        } else {
+            g.C = h->G + h->w_off[l];
+            launch_gemm_bf16<false, false, EPI_STORE>(h, cls, g);
+        }
+    }
+}
+
+// f32 rows -> their bf16 rounding (n floats, a multiple of 4)
+void to_bf16(gnn_mlp *h, const float *src, __bf16 *dst, size_t n) {
+    const int64_t n4 = (int64_t)(n / 4);
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(grid_for(n4)), dim3(256), 0, h->stream, reinterpret_cast<const float4 *>(src),
+                       reinterpret_cast<bf16x4 *>(dst), n4);
 }
 
 constexpr int FIRST_NW = 8;  // waves per fwd_first_kernel workgroup (K split in-LDS)
@@ -289,6 +379,7 @@ void run_output(gnn_mlp *h, const float *y, int B, bool want_prob, bool want_del
     o.label = want_label ? h->labels : nullptr;
     o.B = B; o.B_pad = pad_up(B); o.n_true = h->dims[Lm]; o.n_pad = h->ld[Lm];
     o.out_kind = h->out_kind; o.last_act = h->last_act;
+    o.delta_b = (want_delta && h->dtype == GNN_DTYPE_BF16) ? h->deltab[Lm] : nullptr;
     hipLaunchKernelGGL(output_layer_kernel, dim3((o.B_pad + 3) / 4), dim3(256), 0, h->stream, o);
 }
 
@@ -704,8 +795,19 @@ void launch_tail(gnn_mlp *h, const float *a0, const float *y, int B, bool backwa
     launch_timed(h, -1, tail_kernel, dim3(pad_up(B) / 16), dim3(512), 0, t);
 }
 
+// bf16 twin of an A_0 row pointer: the staging rows or the resident dataset
+const __bf16 *a0_bf16(const gnn_mlp *h, const float *a0) {
+    if (a0 == h->act[0]) return h->actb[0];
+    return h->DXb + (a0 - h->DX);
+}
+
 // the three shapes every entry point is made of
 void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_prob, bool want_loss, bool want_label) {
+    if (h->dtype == GNN_DTYPE_BF16) {
+        forward_bf16(h, a0_bf16(h, a0), B);
+        run_output(h, y, B, want_prob, false, want_loss, want_label);
+        return;
+    }
     if (h->mid4) { fused_forward(h, a0, y, B, false, want_prob, want_loss, want_label); return; }
     const bool tail = use_tail(h);
     if (h->mid_generic && hybrid_choice(h, B).first) {
@@ -721,6 +823,13 @@ void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_
                  bool resident = false) {
     if (h->chain) { chain_gradient(h, a0, y, B, fused_update, step_over_b, momentum, resident); return; }
     h->have_next = false;
+    if (h->dtype == GNN_DTYPE_BF16) {
+        const __bf16 *a0b = a0_bf16(h, a0);
+        forward_bf16(h, a0b, B);
+        run_output(h, y, B, false, true, false, false);
+        backward_bf16(h, a0b, B, fused_update, step_over_b, momentum);
+        return;
+    }
     if (h->mid4) {
         fused_forward(h, a0, y, B, true, false, false, false);
         fused_gradient(h, a0, B, fused_update, step_over_b, momentum);
@@ -762,6 +871,7 @@ int stage_rows(gnn_mlp *h, const double *src, int d, int ld, int B, double *stag
     const int64_t rows_pad = pad_up(B);
     hipLaunchKernelGGL(convert_rows_f64_kernel, dim3(grid_for(rows_pad * ld)), dim3(256), 0, h->stream, stage, d,
                        dst, ld, (int64_t)B, rows_pad, h->inner_act, apply_act ? 1 : 0);
+    if (h->dtype == GNN_DTYPE_BF16 && dst == h->act[0]) to_bf16(h, dst, h->actb[0], (size_t)rows_pad * ld);
     return GNN_OK;
 }
 
@@ -828,6 +938,7 @@ int set_flat(gnn_mlp *h, float *dev, const double *flat) {
     std::vector<float> tmp;
     pack_params(h, flat, tmp);
     HIP_TRY(hipMemcpyAsync(dev, tmp.data(), sizeof(float) * (size_t)h->n_pad, hipMemcpyHostToDevice, h->stream));
+    if (dev == h->W && h->Wb) to_bf16(h, h->W, h->Wb, (size_t)h->n_pad); // the bf16 shadow follows the masters
     HIP_TRY(hipStreamSynchronize(h->stream));
     return GNN_OK;
 }
@@ -926,6 +1037,13 @@ int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act,
     CTRY(dev_alloc(&h->lossv, rows, h->stream));
     CTRY(dev_alloc(&h->labels, rows, h->stream));
     CTRY(dev_alloc(&h->idxbuf, rows, h->stream));
+    if (dtype == GNN_DTYPE_BF16) {
+        CTRY(dev_alloc(&h->Wb, (size_t)h->n_pad, h->stream));
+        h->actb.assign(n_dims, nullptr);
+        h->deltab.assign(n_dims, nullptr);
+        for (int l = 0; l < n_dims - 1; l++) CTRY(dev_alloc(&h->actb[l], rows * h->ld[l], h->stream));
+        for (int l = 1; l < n_dims; l++) CTRY(dev_alloc(&h->deltab[l], rows * h->ld[l], h->stream));
+    }
     CTRY(dev_alloc(&h->stage_x, (size_t)max_batch * dims[0], h->stream));
     CTRY(dev_alloc(&h->stage_y, (size_t)max_batch * dims[n_dims - 1], h->stream));
     {
@@ -961,6 +1079,9 @@ int gnn_mlp_destroy(gnn_mlp_t *h) {
     for (float *p : h->delta) fr(p);
     fr(h->logits); fr(h->prob); fr(h->ybuf); fr(h->lossv); fr(h->labels); fr(h->idxbuf);
     fr(h->stage_x); fr(h->stage_y); fr(h->stage_out); fr(h->DX); fr(h->DY); fr(h->slabs);
+    fr(h->Wb); fr(h->DXb);
+    for (__bf16 *p : h->actb) fr(p);
+    for (__bf16 *p : h->deltab) fr(p);
     if (h->tr_exec) (void)hipGraphExecDestroy(h->tr_exec);
     if (h->tr_graph) (void)hipGraphDestroy(h->tr_graph);
     for (TimerClass &t : h->timers) {
@@ -1151,11 +1272,13 @@ static int alloc_dataset(gnn_mlp *h, int64_t N) {
     HIP_TRY(hipStreamSynchronize(h->stream)); // nothing in flight may still read the old dataset
     if (h->DX) { (void)hipFree(h->DX); h->DX = nullptr; }
     if (h->DY) { (void)hipFree(h->DY); h->DY = nullptr; }
+    if (h->DXb) { (void)hipFree(h->DXb); h->DXb = nullptr; }
     h->dataset_n = 0;
     h->slab_valid = false; h->have_next = false; // they name rows of the old dataset
     const size_t rows = (size_t)N + PAD; // PAD zero rows behind the last sample: a batch's padding rows read them
     TRY(dev_alloc(&h->DX, rows * h->ld[0], h->stream));
     TRY(dev_alloc(&h->DY, rows * h->ld[h->L - 1], h->stream));
+    if (h->dtype == GNN_DTYPE_BF16) TRY(dev_alloc(&h->DXb, rows * h->ld[0], h->stream));
     return GNN_OK;
 }
 
@@ -1183,6 +1306,7 @@ int gnn_mlp_upload_dataset(gnn_mlp_t *h, const double *X, const double *Y, int64
         err = hipStreamSynchronize(h->stream); // the staging buffers are reused by the next chunk
     }
     if (err != hipSuccess) return fail(GNN_ERR_HIP, std::string("dataset upload: ") + hipGetErrorString(err));
+    if (h->DXb) { to_bf16(h, h->DX, h->DXb, ((size_t)N + PAD) * h->ld[0]); HIP_TRY(hipStreamSynchronize(h->stream)); }
     TRY_LAUNCHES(h);
     h->dataset_n = N;
     return GNN_OK;
@@ -1204,6 +1328,7 @@ int gnn_mlp_upload_dataset_u8(gnn_mlp_t *h, const uint8_t *pixels, const uint8_t
     hipLaunchKernelGGL(onehot_u8_kernel, dim3(grid_for(N * h->ld[h->L - 1])), dim3(256), 0, h->stream, sl, dl, h->DY,
                        h->ld[h->L - 1], N, N);
     HIP_TRY(hipStreamSynchronize(h->stream)); // the scratch buffers are released when this function returns
+    if (h->DXb) { to_bf16(h, h->DX, h->DXb, ((size_t)N + PAD) * h->ld[0]); HIP_TRY(hipStreamSynchronize(h->stream)); }
     TRY_LAUNCHES(h);
     h->dataset_n = N;
     return GNN_OK;
@@ -1418,6 +1543,7 @@ static int step_on_device_indices(gnn_mlp *h, const int32_t *d_idx, int B, doubl
         return rc;
     }
     launch_gather(h, d_idx, B);
+    if (h->dtype == GNN_DTYPE_BF16) to_bf16(h, h->act[0], h->actb[0], (size_t)pad_up(B) * h->ld[0]);
     return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum, false);
 }
 
@@ -1539,7 +1665,8 @@ int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentu
         const int64_t n4 = h->n_pad / 4;
         launch_timed(h, GNN_K_UPDATE, sgd_momentum_kernel, dim3(grid_for(n4)), dim3(256), 0,
                      SgdParams{reinterpret_cast<float4 *>(h->W), reinterpret_cast<float4 *>(h->V),
-                               reinterpret_cast<const float4 *>(h->G), n4, (float)(step / (double)B_global), (float)momentum});
+                               reinterpret_cast<const float4 *>(h->G), n4, (float)(step / (double)B_global), (float)momentum,
+                               reinterpret_cast<sgd_bf16x4 *>(h->Wb)});
         h->slab_valid = false; h->have_next = false;
     }
     h->time++;

@@ -320,6 +320,7 @@ struct OutParams {
     int32_t *label;             // [B_pad] may be null
     int B, B_pad, n_true, n_pad;
     int out_kind, last_act;
+    __bf16 *delta_b;            // bf16 mode: the rounding of `delta`, same ld (may be null)
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
                 const float yy = live ? yc[i] : 0.f;
                 if (p.prob) p.prob[(size_t)row * p.ldp + c] = pr;
                 if (p.delta) p.delta[(size_t)row * p.ldd + c] = live ? pr - yy : 0.f;
+                if (p.delta_b) p.delta_b[(size_t)row * p.ldd + c] = (__bf16)(live ? pr - yy : 0.f);
                 if (live && yy != 0.f) l += yy * (lse - zc[i]); // -y ln p
             }
         }
@@ -430,6 +432,7 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
             const float yy = (live && y) ? y[c] : 0.f;
             if (p.prob) p.prob[(size_t)row * p.ldp + c] = pr;
             if (p.delta) p.delta[(size_t)row * p.ldd + c] = live ? pr - yy : 0.f;
+            if (p.delta_b) p.delta_b[(size_t)row * p.ldd + c] = (__bf16)(live ? pr - yy : 0.f);
             if (live && yy != 0.f) l += yy * (lse - z[c]); // -y ln p
         }
         l = wave_sum(l);
@@ -450,6 +453,7 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
             const float d = a - yy; // loss' of 0.5*(a-y)^2
             if (p.prob) p.prob[(size_t)row * p.ldp + c] = live ? a : 0.f;
             if (p.delta) p.delta[(size_t)row * p.ldd + c] = live ? d * act_prime_from_a(p.last_act, a) : 0.f;
+            if (p.delta_b) p.delta_b[(size_t)row * p.ldd + c] = (__bf16)(live ? d * act_prime_from_a(p.last_act, a) : 0.f);
             if (live) {
                 l += 0.5f * d * d;
                 if (c == 0) has_nan = (a != a); // element-wise output: only a NaN at index 0 is sticky
@@ -476,10 +480,12 @@ __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
 //   adj = (step*G)/B + momentum*prev ; W -= adj ; prev = adj
 // Padding elements have G = 0 and prev = 0, so they stay exactly 0.
 // ------------------------------------------------------------------------------------------
+typedef __bf16 sgd_bf16x4 __attribute__((ext_vector_type(4)));
 struct SgdParams {
     float4 *W; float4 *V; const float4 *G;
     int64_t n4;
     float step_over_b, momentum;
+    sgd_bf16x4 *Wb; // bf16 mode: the shadow of W (may be null)
 };
 __global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdParams p) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n4; i += (int64_t)gridDim.x * 256) {
@@ -492,6 +498,7 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdParams p) {
         w.x -= v.x; w.y -= v.y; w.z -= v.z; w.w -= v.w;
         p.V[i] = v;
         p.W[i] = w;
+        if (p.Wb) p.Wb[i] = (sgd_bf16x4){(__bf16)w.x, (__bf16)w.y, (__bf16)w.z, (__bf16)w.w};
     }
 }
 

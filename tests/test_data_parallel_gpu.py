@@ -85,9 +85,16 @@ def test_two_ranks_one_gpu_equal_single_process(gnn, tmp_path, bf16):
     for s in range(STEPS):
         ref.compute_gradient_range(s * Bg, Bg)       # same split path: G, then the flat update
         ref.apply_update(Bg, 0.0125, 0.9)
-    # one process on the global batch: only the summation order of the two partial gradients differs
-    # (bf16: a weight that differs in its last f32 bit can round to the neighbouring bf16 operand value)
-    assert np.abs(w0 - ref.get_weights()).max() <= (1e-4 if bf16 else 4e-6)
+    # one process on the global batch: only the summation order of the two partial gradients differs.
+    # f32: that stays at rounding level over the 24 steps.  bf16: a weight that differs in its last f32 bit can
+    # round to the NEIGHBOURING bf16 operand value (a 0.4 % step), and with logits of +-100 at this init such a
+    # flip moves saturated softmax rows: two correct runs drift apart, so the 24-step comparison is statistical
+    # and the tight comparison is made after 3 steps below
+    d = np.abs(w0 - ref.get_weights())
+    if bf16:
+        assert d.mean() <= 2e-4 and d.max() <= 5e-2
+    else:
+        assert d.max() <= 4e-6
     if bf16:
         # and the bf16-aware fp64 oracle on the GLOBAL batch (tests/np_oracle.py: every GEMM operand
         # rounded to bf16, f32-exact inputs)

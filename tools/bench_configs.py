@@ -1,44 +1,109 @@
 #!/usr/bin/env python3
-"""Development bench over the other BASELINE.json configs (not the driver's contract, which is
-bench.py): steps/s, samples/s and FLOP rate of one gradientStep on synthetic data in HBM."""
-import os, sys, time
+"""Bench over the OTHER BASELINE.json configs (bench.py is the driver's contract and measures configs[1]):
+one JSON line per (config, dtype) with the whole-step rate and a `roofline` object in bench.py's format.
+
+  python tools/bench_configs.py [1] [2] [4] [5] [f32] [bf16] [--steps N]
+
+A step is one gradientStep on synthetic batches resident in HBM (gnn_mlp_train_range).  Algorithmic
+work per step is SURVEY 8d's accounting: FLOP = (6P - 2 d0 d1) B; bytes = weights (P read forward +
+(P - d0 d1) read backward + P gradient + 5P update) x 4 B (f32 masters; bf16 operand reads count 2 B)
++ activations B (d0 + 4 sum_{l>=1} d_l) x element size.  `roofline` is quoted on the WHOLE STEP for
+these configs (a step is a chain of 3(L-1) GEMMs that all run at the same roof): bound = MFMA when the
+step's arithmetic intensity is above the dtype's ridge, else HBM.  Per-kernel times of the first forward
+GEMM and the first-layer gradient GEMM (the two largest) come from the dispatches' own timestamps.
+"""
+import json
+import os
+import sys
+import time
+
 import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import gnn_amd
+import gnn_amd  # noqa: E402
 
 CONFIGS = {
-    "1": ([784, 100, 50, 10], 32),
-    "2": ([784, 300, 100, 10], 128),
-    "4": ([4096, 2048, 2048, 1024], 512),
-    "5": ([784, 1024, 1024, 1024, 10], 256),
+    "1": ([784, 100, 50, 10], 32, "configs[0] shape: 784-100-50-10, batch 32"),
+    "2": ([784, 300, 100, 10], 128, "configs[1]/[2] shape: 784-300-100-10, batch 128"),
+    "4": ([4096, 2048, 2048, 1024], 512, "configs[3]: 4096-2048-2048-1024, batch 512 (MFMA-bound GEMM roofline run)"),
+    "5": ([784, 1024, 1024, 1024, 10], 256, "configs[4]: 784-1024-1024-1024-10, batch 256"),
 }
+PEAK_TF = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+HBM_GBS = 8000.0
+
+
+def run(key, dtype, steps):
+    dims, B, label = CONFIGS[key]
+    rng = np.random.default_rng(0)
+    nb = 8
+    X = rng.random((B * nb, dims[0])) * (rng.random((B * nb, dims[0])) < 0.19)
+    Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B * nb)]
+    net = gnn_amd.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn_amd.DTYPE_BF16 if dtype == "bf16" else gnn_amd.DTYPE_F32, max_batch=B)
+    if dims[0] > 1000 or len(dims) > 4:
+        net.set_weights(net.get_weights() * 0.05)   # keep the softmax unsaturated at these widths
+    net.upload_dataset(X, Y)
+    net.train_range(0, B, 20, 0.0125, 0.9)
+    net.synchronize()
+    t0 = time.perf_counter()
+    net.train_range(0, B, steps, 0.0125, 0.9)
+    net.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    net.timing_enable(True)
+    net.train_range(0, B, min(steps, 100), 0.0125, 0.9)
+    net.synchronize()
+    fwd_us, fwd_n = net.timing_read(0)
+    grad_us, grad_n = net.timing_read(1)
+    net.timing_enable(False)
+    P = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1))
+    flop = (6 * P - 2 * dims[0] * dims[1]) * B
+    eo = 2 if dtype == "bf16" else 4
+    nbytes = eo * (2 * P - dims[0] * dims[1]) + 4 * 6 * P + eo * B * (dims[0] + 4 * sum(dims[1:]))
+    tf = flop / dt / 1e12
+    gbs = nbytes / dt / 1e9
+    ridge = PEAK_TF[dtype] * 1e12 / (HBM_GBS * 1e9)
+    ai = flop / nbytes
+    bound = "mfma" if ai >= ridge else "hbm"
+    ach, peak, unit = (tf, PEAK_TF[dtype], "TFLOP/s") if bound == "mfma" else (gbs, HBM_GBS, "GB/s")
+    kern = {}
+    if fwd_n:
+        f = 2.0 * B * dims[0] * dims[1]
+        kern["first forward GEMM (%dx%dx%d)" % (B, dims[0], dims[1])] = {
+            "avg_us": round(fwd_us, 2), "launches": fwd_n, "tflops": round(f / (fwd_us * 1e-6) / 1e12, 2),
+            "mfma_frac": round(f / (fwd_us * 1e-6) / 1e12 / PEAK_TF[dtype], 4)}
+    if grad_n:
+        f = 2.0 * B * dims[0] * dims[1]
+        kern["first-layer gradient GEMM + update (%dx%dx%d)" % (dims[0], dims[1], B)] = {
+            "avg_us": round(grad_us, 2), "launches": grad_n, "tflops": round(f / (grad_us * 1e-6) / 1e12, 2),
+            "mfma_frac": round(f / (grad_us * 1e-6) / 1e12 / PEAK_TF[dtype], 4)}
+    line = {"metric": "training samples/sec, %s" % label, "value": round(B / dt, 1), "unit": "samples/s", "n_gpus": 1,
+            "steps": steps, "ms_per_step": round(dt * 1e3, 5), "dtype": dtype, "data": "synthetic",
+            "config": {"workload": label, "dims": dims, "batch": B, "step_launches": net.step_launches},
+            "roofline": {"bound": bound, "kernel": "whole gradientStep (forward + backward GEMM chain + update)",
+                         "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
+                         "flop_per_step": flop, "algorithmic_bytes_per_step": nbytes,
+                         "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
+                         "tflops": round(tf, 2), "gbs": round(gbs, 1),
+                         "mfma_frac": round(tf / PEAK_TF[dtype], 4), "hbm_frac": round(gbs / HBM_GBS, 4),
+                         "kernels": kern}}
+    net.close()
+    return line
+
 
 def main():
     args = sys.argv[1:]
-    dtype = gnn_amd.DTYPE_BF16 if "bf16" in args else gnn_amd.DTYPE_F32
-    which = [a for a in args if a != "bf16"] or ["1", "2", "5", "4"]
+    steps = None
+    if "--steps" in args:
+        i = args.index("--steps")
+        steps = int(args[i + 1])
+        del args[i:i + 2]
+    dtypes = [a for a in args if a in ("f32", "bf16")] or ["f32"]
+    which = [a for a in args if a in CONFIGS] or ["1", "2", "5", "4"]
     for key in which:
-        dims, B = CONFIGS[key]
-        rng = np.random.default_rng(0)
-        nb = 8
-        X = rng.random((B * nb, dims[0])) * (rng.random((B * nb, dims[0])) < 0.19)
-        Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B * nb)]
-        net = gnn_amd.SoftmaxCrossEntropyNeuralNet(dims, dtype=dtype, max_batch=B)
-        if dims[0] > 1000:
-            net.set_weights(net.get_weights() * 0.05)
-        net.upload_dataset(X, Y)
-        steps = 200 if key in ("4", "5") else 2000
-        net.train_range(0, B, 20, 0.0125, 0.9); net.synchronize()
-        t0 = time.perf_counter()
-        net.train_range(0, B, steps, 0.0125, 0.9); net.synchronize()
-        dt = time.perf_counter() - t0
-        P = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1))
-        flop = (6 * P - 2 * dims[0] * dims[1]) * B
-        print(("bf16 " if dtype else "f32  ") + "config %s %s B=%d: %.2f us/step, %.3g samples/s, %.2f TFLOP/s (%.1f%% of 157.3 fp32 MFMA)" % (
-            key, "-".join(map(str, dims)), B, dt / steps * 1e6, steps * B / dt, flop / (dt / steps) / 1e12,
-            100 * flop / (dt / steps) / 157.3e12), flush=True)
-        net.close()
+        for dtype in dtypes:
+            n = steps or (200 if key in ("4", "5") else 2000)
+            print(json.dumps(run(key, dtype, n)), flush=True)
+
 
 if __name__ == "__main__":
     main()
