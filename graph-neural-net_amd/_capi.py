@@ -61,6 +61,17 @@ SYMBOLS = [
     ("gnn_mlp_apply_update", C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
     ("gnn_mlp_hint_next_range", C.c_int, [_H, C.c_int64, C.c_int]),
     ("gnn_mlp_synchronize", C.c_int, [_H]),
+    ("gnn_mlp_dp_create", C.c_int, [_ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
+    ("gnn_mlp_dp_destroy", C.c_int, [_H]),
+    ("gnn_mlp_dp_num_replicas", C.c_int, [_H]),
+    ("gnn_mlp_dp_replica", C.c_int, [_H, C.c_int, C.POINTER(_H)]),
+    ("gnn_mlp_dp_gradient_step", C.c_int, [_H, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_int]),
+    ("gnn_mlp_dp_upload_dataset", C.c_int, [_H, _dp, _dp, C.c_int64]),
+    ("gnn_mlp_dp_gradient_step_range", C.c_int, [_H, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int]),
+    ("gnn_mlp_dp_train_range", C.c_int, [_H, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double]),
+    ("gnn_mlp_dp_set_weights", C.c_int, [_H, _dp]),
+    ("gnn_mlp_dp_synchronize", C.c_int, [_H]),
+    ("gnn_mlp_dp_replicas_identical", C.c_int, [_H, C.POINTER(C.c_int)]),
     ("gnn_mlp_advance_time", C.c_int, [_H, C.c_int]),
     ("gnn_mlp_recover_stream", C.c_int, [_H]),
     ("gnn_mlp_specialize", C.c_int, [_H]),

@@ -7,8 +7,8 @@
 //   act[l] / actb[l]        f(z_l) in f32 (f' is taken from it, host exports) and its bf16 rounding (GEMM operand)
 //   delta[l] / deltab[l]    dE/dz_l in f32 and bf16
 // Every producer rounds ONCE (v_cvt_pk_bf16_f32, round-to-nearest-even) in its epilogue, so a GEMM
-// moves half the operand bytes and converts nothing.  Arithmetic contract = tests/np_oracle.py *_bf16:
-// every GEMM operand rounded to bf16, products exact, f32 accumulation.
+// moves half the operand bytes and converts nothing.  Arithmetic contract (what the bf16 parity tests restate
+// in fp64): every GEMM operand rounded to bf16, products exact, f32 accumulation.
 //
 // All three products read their operands in the NATURAL layouts (no transposed copies in HBM):
 //   forward   Z  = A . W        A [B][d_in] k-contiguous,   W [d_in][d_out] k-major

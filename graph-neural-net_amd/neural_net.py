@@ -313,3 +313,130 @@ class GeneralNeuralNet(NeuralNet):
                  seed=1, dtype=DTYPE_F32, device=0, max_batch=1024):
         super().__init__(layer_dims, OUT_ACT_LOSS, inner_act, last_act, loss, seed=seed, dtype=dtype,
                          device=device, max_batch=max_batch)
+
+
+REDUCE_RCCL, REDUCE_DIRECT = 0, 1
+
+
+class _ReplicaView(NeuralNet):
+    """A replica of a DataParallelNeuralNet seen through the single-net interface (borrowed handle:
+    closing the view does not destroy it)."""
+
+    def __init__(self, lib, handle, layer_dims, max_batch):
+        self._lib, self._h = lib, handle
+        self.layer_dims = list(layer_dims)
+        self.max_batch = max_batch
+        self.n_params = lib.gnn_mlp_num_params(handle)
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+class DataParallelNeuralNet:
+    """The NeuralNet interface over gnn_mlp_dp_* (include/gnn_mlp.h): ONE object, N device replicas,
+    gradientStep sharded by rows inside the library (what a single-threaded JVM caller uses; the
+    one-process-per-GPU form is data_parallel.py).  propagate / calculateLoss / argmax run on replica 0
+    (all replicas are bitwise identical)."""
+
+    def __init__(self, layer_dims, devices=(0,), out_kind=OUT_SOFTMAX_CE, inner_act=ACT_LEAKY_RELU,
+                 last_act=ACT_IDENTITY, loss=LOSS_HALF_SQUARED, seed=1, dtype=DTYPE_F32, max_batch=1024,
+                 reducer=REDUCE_RCCL):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        dims = [int(d) for d in layer_dims]
+        devs = [int(d) for d in devices]
+        _capi.check(self._lib.gnn_mlp_dp_create((C.c_int32 * len(dims))(*dims), len(dims), out_kind, _act(inner_act),
+                                                _act(last_act), loss, seed, dtype, (C.c_int32 * len(devs))(*devs),
+                                                len(devs), max_batch, reducer, C.byref(self._h)))
+        self.layer_dims, self.devices, self.max_batch = dims, devs, max_batch
+        self.replicas = []
+        for r in range(len(devs)):
+            h = C.c_void_p()
+            _capi.check(self._lib.gnn_mlp_dp_replica(self._h, r, C.byref(h)))
+            self.replicas.append(_ReplicaView(self._lib, h, dims, max_batch))
+        self.n_params = self.replicas[0].n_params
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            for v in self.replicas:
+                v.close()
+            self._lib.gnn_mlp_dp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # NeuralNet.java
+    def getInputDim(self):
+        return self.layer_dims[0]
+
+    def getOutputDim(self):
+        return self.layer_dims[-1]
+
+    def propagate(self, input):
+        return self.replicas[0].propagate(input)
+
+    def calculateLoss(self, input, expected):
+        return self.replicas[0].calculateLoss(input, expected)
+
+    def calculateWeightGradient(self, input, expected):
+        return self.replicas[0].calculateWeightGradient(input, expected)
+
+    def argmax(self, input):
+        return self.replicas[0].argmax(input)
+
+    def gradientStep(self, batch, step, momentum, noise=False, expected=None):
+        """NN:51, the rows dealt to the replicas in contiguous blocks."""
+        if expected is None:
+            items = list(batch.items()) if hasattr(batch, "items") else list(batch)
+            if not items:
+                raise ValueError("batch must be non-empty (SCE:300)")
+            X = np.stack([np.asarray(k, dtype=np.float64) for k, _ in items])
+            Y = np.stack([np.asarray(v, dtype=np.float64) for _, v in items])
+        else:
+            X, Y = batch, expected
+        X = _f64(X, self.layer_dims[0])
+        Y = _f64(Y, self.layer_dims[-1])
+        if X.shape[0] != Y.shape[0]:
+            raise ValueError("input / expected row counts differ")
+        _capi.check(self._lib.gnn_mlp_dp_gradient_step(self._h, _dp(X), _dp(Y), X.shape[0], float(step),
+                                                       float(momentum), int(bool(noise))))
+
+    gradient_step = gradientStep
+
+    def upload_dataset(self, X, Y):
+        X = _f64(X, self.layer_dims[0])
+        Y = _f64(Y, self.layer_dims[-1])
+        _capi.check(self._lib.gnn_mlp_dp_upload_dataset(self._h, _dp(X), _dp(Y), X.shape[0]))
+
+    def gradient_step_range(self, first, B, step, momentum, noise=False):
+        _capi.check(self._lib.gnn_mlp_dp_gradient_step_range(self._h, int(first), int(B), float(step), float(momentum),
+                                                             int(bool(noise))))
+
+    def train_range(self, first, B, n_steps, step, momentum):
+        _capi.check(self._lib.gnn_mlp_dp_train_range(self._h, int(first), int(B), int(n_steps), float(step), float(momentum)))
+
+    def set_weights(self, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float64).ravel()
+        _capi.check(self._lib.gnn_mlp_dp_set_weights(self._h, _dp(flat)))
+
+    def get_weights(self):
+        return self.replicas[0].get_weights()
+
+    def get_momentum(self):
+        return self.replicas[0].get_momentum()
+
+    @property
+    def time(self):
+        return self.replicas[0].time
+
+    def synchronize(self):
+        _capi.check(self._lib.gnn_mlp_dp_synchronize(self._h))
+
+    def replicas_identical(self):
+        out = C.c_int()
+        _capi.check(self._lib.gnn_mlp_dp_replicas_identical(self._h, C.byref(out)))
+        return bool(out.value)

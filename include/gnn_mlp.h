@@ -23,7 +23,7 @@
  *    row-major [in][out] like `weights.get(l)[in][out]` (SCE:44-47), UNPADDED, fp64 on the host.
  *  - the library never keeps a host pointer past the call (the reference aliases the caller's
  *    input array in neurons[0], SCE:167-168; no caller can observe that through NN:16-65).
- *  - one handle = one GPU = one logical stream of calls; calls on one handle must be serialised
+ *  - one gnn_mlp_t = one GPU = one logical stream of calls (gnn_mlp_dp_t: one handle over N GPUs); calls on one handle must be serialised
  *    by the caller (the reference classes are not re-entrant either: `neurons` is shared scratch).
  *  - there is NO CPU fallback: with no gfx950 device every entry point fails with
  *    GNN_ERR_NO_DEVICE.
@@ -207,6 +207,40 @@ int gnn_mlp_advance_time(gnn_mlp_t *h, int steps);
  * in the invalidated state the handle returns to its own stream and the caller binds a fresh one
  * with gnn_mlp_set_stream. No reference counterpart. */
 int gnn_mlp_recover_stream(gnn_mlp_t *h);
+
+/* ---- data parallel INSIDE the library: one handle, N device replicas -------------------------------
+ * For a caller that is one thread in one process (the reference: NeuralNetTrainer calls gradientStep from
+ * the JVM's main thread, NNT:83).  The batch's rows are dealt to the replicas in contiguous blocks, every
+ * replica forms the partial gradient of its rows (the per-sample loop SCE:305-322 restricted to them), the
+ * flat gradient buffers are summed across the devices, and every replica applies the identical update with
+ * batchSize = B (SCE:333): replicas stay bitwise identical.  `max_batch` bounds the GLOBAL batch.
+ *   GNN_REDUCE_RCCL   : ncclCommInitAll + one ncclAllReduce(SUM) per replica per step (RCCL over xGMI);
+ *                       RCCL is loaded at run time (dlopen), one distinct device per replica.
+ *   GNN_REDUCE_DIRECT : peer-mapped gradient buffers, stream events between the devices, ONE kernel per
+ *                       replica that sums all partial gradients in rank order and updates (no collective
+ *                       library; replicas may share a device, which is how it is tested on one GPU).
+ * Everything that is per net (propagate, loss, argmax, get/set of weights, checkpoint) goes through a
+ * replica's own handle, gnn_mlp_dp_replica(h, r, &net) -- borrowed, never destroyed by the caller. */
+typedef struct gnn_mlp_dp gnn_mlp_dp_t;
+typedef enum { GNN_REDUCE_RCCL = 0, GNN_REDUCE_DIRECT = 1 } gnn_reducer;
+int gnn_mlp_dp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act, int last_act, int loss,
+                      int64_t seed, int dtype, const int32_t *devices, int n_dev, int max_batch, int reducer,
+                      gnn_mlp_dp_t **out);
+int gnn_mlp_dp_destroy(gnn_mlp_dp_t *h);
+int gnn_mlp_dp_num_replicas(const gnn_mlp_dp_t *h);
+int gnn_mlp_dp_replica(gnn_mlp_dp_t *h, int r, gnn_mlp_t **out);
+/* NN:51 gradientStep, sharded over the replicas. */
+int gnn_mlp_dp_gradient_step(gnn_mlp_dp_t *h, const double *X, const double *Y, int B, double step,
+                             double momentum, int noise);
+/* Every replica keeps the whole training set (NNT:28-43): any batch of it can then be sharded in place. */
+int gnn_mlp_dp_upload_dataset(gnn_mlp_dp_t *h, const double *X, const double *Y, int64_t N);
+int gnn_mlp_dp_gradient_step_range(gnn_mlp_dp_t *h, int64_t first, int B, double step, double momentum,
+                                   int noise);
+int gnn_mlp_dp_train_range(gnn_mlp_dp_t *h, int64_t first, int B, int n_steps, double step, double momentum);
+int gnn_mlp_dp_set_weights(gnn_mlp_dp_t *h, const double *flat);
+int gnn_mlp_dp_synchronize(gnn_mlp_dp_t *h);
+/* *identical = 1 when every replica holds the same weights, momentum and step count, bit for bit. */
+int gnn_mlp_dp_replicas_identical(gnn_mlp_dp_t *h, int *identical);
 
 /* ---- shape specialisation ---------------------------------------------------------------------
  * The per-row-block kernel of the fused small-net path is a template over the net's shape; with

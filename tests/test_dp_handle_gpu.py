@@ -1,0 +1,92 @@
+"""gnn_mlp_dp_*: ONE handle over N device replicas, the data-parallel gradientStep inside the library
+(the reference's caller is a single thread, NNT:83).  On the one-GPU box:
+  * GNN_REDUCE_RCCL with n_dev = 1 (ncclCommInitAll + ncclAllReduce of the flat gradient on a world of one);
+  * GNN_REDUCE_DIRECT with 2, 3 and 4 replicas that SHARE device 0: peer pointers, stream events between the
+    replicas' streams and the rank-ordered sum + update kernel are exercised exactly as across devices.
+Checks: replicas bitwise identical; equal to ONE net stepping on the whole batch up to the summation
+order of the partial gradients; ragged shards (B not divisible, B < replicas); both dtypes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DIMS = [784, 300, 100, 10]
+
+
+def data(n, seed=5):
+    rng = np.random.default_rng(seed)
+    X = rng.random((n, DIMS[0])) * (rng.random((n, DIMS[0])) < 0.3)
+    Y = np.eye(DIMS[-1])[rng.integers(0, DIMS[-1], n)]
+    return X, Y
+
+
+def single_net_reference(gnn, X, Y, B, steps, dtype):
+    ref = gnn.SoftmaxCrossEntropyNeuralNet(DIMS, max_batch=B, dtype=dtype)
+    ref.upload_dataset(X, Y)
+    nb = X.shape[0] // B
+    for s in range(steps):
+        ref.compute_gradient_range((s % nb) * B, B)     # the split path: gradient buffer, then the flat update
+        ref.apply_update(B, 0.0125, 0.9)
+    return ref
+
+
+def test_rccl_world_of_one(gnn):
+    B, steps = 96, 6
+    X, Y = data(B * 3)
+    net = gnn.DataParallelNeuralNet(DIMS, devices=[0], max_batch=B, reducer=gnn.REDUCE_RCCL)
+    net.upload_dataset(X, Y)
+    net.train_range(0, B, steps, 0.0125, 0.9)
+    assert net.time == steps and net.replicas_identical()
+    ref = single_net_reference(gnn, X, Y, B, steps, gnn.DTYPE_F32)
+    assert np.array_equal(net.get_weights(), ref.get_weights())   # one replica: same kernels, same order
+    with pytest.raises(gnn.GnnError, match="distinct device"):
+        gnn.DataParallelNeuralNet(DIMS, devices=[0, 0], max_batch=B, reducer=gnn.REDUCE_RCCL)
+
+
+@pytest.mark.parametrize("n_rep,B", [(2, 128), (3, 100), (4, 64)])
+def test_direct_reducer_replicas_sharing_one_device(gnn, n_rep, B):
+    steps = 7
+    X, Y = data(B * 3, seed=n_rep)
+    net = gnn.DataParallelNeuralNet(DIMS, devices=[0] * n_rep, max_batch=B, reducer=gnn.REDUCE_DIRECT)
+    assert len(net.replicas) == n_rep
+    net.upload_dataset(X, Y)
+    net.train_range(0, B, steps, 0.0125, 0.9)
+    net.synchronize()
+    assert net.time == steps
+    assert net.replicas_identical()                                # rank-ordered sum: the same bits on every replica
+    ref = single_net_reference(gnn, X, Y, B, steps, gnn.DTYPE_F32)
+    assert np.abs(net.get_weights() - ref.get_weights()).max() <= 2e-6   # only the partial sums' order differs
+    p, pr = net.propagate(X[:B]), ref.propagate(X[:B])
+    assert np.abs(p - pr).max() <= 1e-4
+
+
+def test_host_batches_ragged_shards_and_tiny_batches(gnn, oracle_mod):
+    """NeuralNet.gradientStep(double[] rows) through the dp handle: shard sizes 34/33/33, then a batch
+    smaller than the replica count (a replica with no rows contributes a zero gradient)."""
+    net = gnn.DataParallelNeuralNet(DIMS, devices=[0, 0, 0], max_batch=100, reducer=gnn.REDUCE_DIRECT)
+    ref = oracle_mod.OracleNet(DIMS)
+    ref.set_alloc_per_sample(0)
+    for s, B in enumerate([100, 2, 37, 1]):
+        X, Y = data(B, seed=20 + s)
+        net.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+        ref.gradient_step(X, Y, 0.0125, 0.9)
+    assert net.replicas_identical() and net.time == 4
+    assert np.abs(net.get_weights() - ref.get_weights()).max() <= 4 * 2e-6
+    with pytest.raises(gnn.GnnError):
+        X, Y = data(101)
+        net.gradientStep(X, 0.0125, 0.9, False, expected=Y)        # beyond max_batch
+    with pytest.raises(gnn.GnnError):
+        X, Y = data(4)
+        net.gradientStep(X, 0.0125, 0.9, True, expected=Y)         # noise: unsupported, as on one device
+
+
+def test_direct_reducer_bf16(gnn):
+    """configs[2]'s arithmetic (bf16 operands) sharded inside the library: the bf16 shadow of W follows the
+    masters in the reduce+update kernel; replicas identical, close to one net on the whole batch."""
+    B, steps = 128, 3
+    X, Y = data(B * 2, seed=9)
+    net = gnn.DataParallelNeuralNet(DIMS, devices=[0, 0], max_batch=B, reducer=gnn.REDUCE_DIRECT, dtype=gnn.DTYPE_BF16)
+    net.upload_dataset(X, Y)
+    net.train_range(0, B, steps, 0.0125, 0.9)
+    assert net.replicas_identical()
+    ref = single_net_reference(gnn, X, Y, B, steps, gnn.DTYPE_BF16)
+    assert np.abs(net.get_weights() - ref.get_weights()).max() <= 3e-4
