@@ -124,3 +124,22 @@ def accuracy(net, labels, first=0):
         hits += int((net.argmax_range(first + off, n) == labels[off:off + n]).sum())
         off += n
     return hits / labels.size
+
+
+def train_log_row(net_dim, iterations, step_size, batch_size, momentum, noise, training_acc, test_acc):
+    """The row MNISTTrainer.logTest appends to logs/trainLog.csv (MT:211-219):
+    `dims,iterations,step,batch,momentum,noise,trainAcc,testAcc` in the reference's number formats
+    (`%d`, `%.5f`, `%d`, `%.3f`, Java's boolean text, `%.5f,%.5f`)."""
+    dims = "-".join(str(int(d)) for d in net_dim)
+    return "%s,%d,%.5f,%d,%.3f,%s,%.5f,%.5f\n" % (dims, iterations, step_size, batch_size, momentum,
+                                                 "true" if noise else "false", training_acc, test_acc)
+
+
+def log_test(path, net_dim, iterations, step_size, batch_size, momentum, noise, training_acc, test_acc):
+    """Appends one train_log_row to `path` (the reference opens logs/trainLog.csv in append mode, MT:61)."""
+    import os
+    d = os.path.dirname(str(path))
+    if d:
+        os.makedirs(d, exist_ok=True)
+    with open(path, "a") as f:
+        f.write(train_log_row(net_dim, iterations, step_size, batch_size, momentum, noise, training_acc, test_acc))

@@ -53,3 +53,25 @@ def test_product_package_does_not_import_the_oracle():
             if fn.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in text.lower() or fn == "__none__", "%s mentions the oracle" % fn
+
+
+def test_java_binding_sources_are_complete_and_consistent():
+    """java/ cannot be compiled here (no JDK), but it can be COMPLETE: every `native` method of HipNeuralNet.java
+    has its Java_HipNeuralNet_* function in gnn_mlp_jni.c and vice versa, every gnn_mlp_* the shim calls is
+    declared in include/gnn_mlp.h, and no JNI critical section wraps the (blocking) library calls."""
+    import re
+    java = open(os.path.join(ROOT, "java", "HipNeuralNet.java")).read()
+    shim = open(os.path.join(ROOT, "java", "gnn_mlp_jni.c")).read()
+    header = open(os.path.join(ROOT, "include", "gnn_mlp.h")).read()
+    natives = set(re.findall(r"private static native \w+ (native\w+)\(", java))
+    impl = set(re.findall(r"Java_HipNeuralNet_(native\w+)\(", shim))
+    assert natives and natives == impl, (natives ^ impl)
+    for fn in set(re.findall(r"\b(gnn_mlp_\w+)\(", shim)):
+        assert re.search(r"\b%s\(" % fn, header), fn
+    code = re.sub(r"/\*.*?\*/", "", shim, flags=re.S)      # comments may name what is NOT used
+    assert "GetPrimitiveArrayCritical" not in code
+    for cls in ("HipSoftmaxCrossEntropyNeuralNet", "HipGeneralNeuralNet", "TrainLog"):
+        assert os.path.exists(os.path.join(ROOT, "java", cls + ".java")), cls
+    # the row format of MNISTTrainer.logTest (MT:211-219) as the reference's own log shows it (logs/trainLog.csv:4)
+    tl = open(os.path.join(ROOT, "java", "TrainLog.java")).read()
+    assert '",%d,%.5f,%d,%.3f,"' in tl and '"%.5f,%.5f\\n"' in tl and '"%d,%.2f\\n"' in tl

@@ -245,3 +245,18 @@ def test_golden_fixtures_match_oracle(oracle_mod):
                 assert np.allclose(a[k], b[k], rtol=1e-12, atol=1e-300), (a["name"], k)
             else:
                 assert a[k] == b[k], (a["name"], k)
+
+
+def test_train_log_row_reproduces_the_references_own_log(tmp_path):
+    """tests/golden/reference_trainLog.csv is the reference's logs/trainLog.csv (5 rows of DATA written by
+    MNISTTrainer.logTest, MT:211-219): the row writer must reproduce each row from its parsed fields."""
+    import gnn_amd
+    rows = open(os.path.join(os.path.dirname(__file__), "golden", "reference_trainLog.csv")).read().splitlines()
+    assert len(rows) == 5
+    out = tmp_path / "logs" / "trainLog.csv"
+    for r in rows:
+        dims, it, step, batch, mom, noise, tr, te = r.split(",")
+        args = ([int(d) for d in dims.split("-")], int(it), float(step), int(batch), float(mom), noise == "true", float(tr), float(te))
+        assert gnn_amd.train_log_row(*args) == r + "\n"
+        gnn_amd.log_test(out, *args)
+    assert out.read_text().splitlines() == rows
