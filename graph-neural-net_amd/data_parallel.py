@@ -152,3 +152,86 @@ class GraphedSteps:
         with self.torch.cuda.stream(self.stream):
             self.graph.replay()
         self.stepper.engine.net.advance_time(self.n)
+
+
+class LoopbackGroup:
+    """A host 'loopback' reducer: N ranks inside ONE process (one thread each) behind the part of the
+    torch.distributed interface DataParallelStep uses (all_reduce with SUM / MIN / MAX, get_world_size,
+    get_rank, barrier, ReduceOp).  It exists so that the sharding + reduction + lock-step logic can be
+    run at world sizes 4 and 8 where there are neither 8 GPUs nor a process group; the
+    sum is taken in RANK ORDER, like the library's direct reducer, so every rank gets the same bits.
+    Works on numpy arrays and on anything with .numpy() / .copy_() (CPU torch tensors)."""
+
+    class ReduceOp:
+        SUM, MIN, MAX = "sum", "min", "max"
+
+    def __init__(self, world):
+        import threading
+        self.world = int(world)
+        self._slots = [None] * self.world
+        self._bar = threading.Barrier(self.world)
+        self._local = threading.local()
+
+    def rank_view(self, rank):
+        """The `dist`-like object rank `rank`'s thread passes to DataParallelStep."""
+        return _LoopbackRank(self, int(rank))
+
+    def run(self, fn):
+        """Runs fn(rank, dist_like) on one thread per rank; returns the results in rank order; re-raises
+        the first failure."""
+        import threading
+        out, err = [None] * self.world, [None] * self.world
+
+        def body(r):
+            try:
+                out[r] = fn(r, self.rank_view(r))
+            except BaseException as e:     # a failed rank must not leave the others waiting
+                err[r] = e
+                self._bar.abort()
+        ts = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for e in err:
+            if e is not None and not isinstance(e, __import__("threading").BrokenBarrierError):
+                raise e
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+
+class _LoopbackRank:
+    def __init__(self, group, rank):
+        self.group, self.rank = group, rank
+        self.ReduceOp = LoopbackGroup.ReduceOp
+
+    def get_world_size(self, group=None):
+        return self.group.world
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def barrier(self, group=None):
+        self.group._bar.wait()
+
+    def all_reduce(self, tensor, op="sum", group=None):
+        g = self.group
+        arr = tensor.numpy() if hasattr(tensor, "numpy") else np.asarray(tensor)
+        g._slots[self.rank] = np.array(arr, copy=True)
+        g._bar.wait()                                   # every rank's contribution is in
+        acc = g._slots[0].copy()
+        for r in range(1, g.world):                     # rank order: identical bits on every rank
+            if op == "sum":
+                acc = acc + g._slots[r]
+            elif op == "min":
+                acc = np.minimum(acc, g._slots[r])
+            else:
+                acc = np.maximum(acc, g._slots[r])
+        g._bar.wait()                                   # nobody overwrites a slot another rank still reads
+        if hasattr(tensor, "copy_"):
+            import torch
+            tensor.copy_(torch.from_numpy(acc))
+        else:
+            arr[...] = acc

@@ -103,3 +103,60 @@ def test_two_rank_gloo_equals_single_process(tmp_path, oracle_mod):
         ref.gradient_step(X[s * Bg:(s + 1) * Bg], Y[s * Bg:(s + 1) * Bg], 0.05, 0.9)
     # only the summation order differs (two partial sums instead of one serial sum)
     assert np.abs(w0 - ref.get_weights()).max() < 1e-13
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_loopback_reducer_world_4_and_8(oracle_mod, world):
+    """The sharding + reduction + update logic at the world sizes of the scaling runs (4 and 8 ranks), with the
+    host loopback reducer standing in for RCCL: N ranks in one process, rank-ordered sum.
+    Ragged global batch (not divisible by the world size)."""
+    import torch
+    import gnn_amd  # noqa: F401
+    from gnn_amd import data_parallel as dp
+    Bg, steps = 21, 3
+    X, Y = oracle_mod.synthetic_batch(DIMS, Bg * steps, 99)
+    group = dp.LoopbackGroup(world)
+
+    def rank_body(rank, dist):
+        net = oracle_mod.OracleNet(DIMS)
+        eng = OracleEngine(net, X, Y, torch)
+        stepper = dp.DataParallelStep(eng, dist)
+        assert stepper.world == world and stepper.rank == rank
+        for s in range(steps):
+            lo, hi = dp.shard_rows(Bg, rank, world)
+            # DataParallelStep takes B_global = B_local * world; with ragged shards the update size is passed explicitly
+            eng.compute_gradient_range(s * Bg + lo, hi - lo)
+            dist.all_reduce(eng.grad_tensor, op=dist.ReduceOp.SUM)
+            eng.apply_update(Bg, 0.05, 0.9)
+        assert stepper.replicas_in_lockstep(torch)
+        return net.get_weights()
+    ws = group.run(rank_body)
+    for w in ws[1:]:
+        assert np.array_equal(ws[0], w)
+    ref = oracle_mod.OracleNet(DIMS)
+    for s in range(steps):
+        ref.gradient_step(X[s * Bg:(s + 1) * Bg], Y[s * Bg:(s + 1) * Bg], 0.05, 0.9)
+    assert np.abs(ws[0] - ref.get_weights()).max() < 1e-13
+
+
+def test_loopback_reducer_even_shards_through_the_stepper(oracle_mod):
+    """DataParallelStep.step itself (B_global = B_local * world) over the loopback group, world 4."""
+    import torch
+    import gnn_amd  # noqa: F401
+    from gnn_amd import data_parallel as dp
+    world, B_local, steps = 4, 3, 3
+    Bg = world * B_local
+    X, Y = oracle_mod.synthetic_batch(DIMS, Bg * steps, 7)
+
+    def rank_body(rank, dist):
+        net = oracle_mod.OracleNet(DIMS)
+        stepper = dp.DataParallelStep(OracleEngine(net, X, Y, torch), dist)
+        for s in range(steps):
+            stepper.step(s * Bg + rank * B_local, B_local, 0.05, 0.9)
+        return net.get_weights()
+    ws = dp.LoopbackGroup(world).run(rank_body)
+    ref = oracle_mod.OracleNet(DIMS)
+    for s in range(steps):
+        ref.gradient_step(X[s * Bg:(s + 1) * Bg], Y[s * Bg:(s + 1) * Bg], 0.05, 0.9)
+    assert all(np.array_equal(ws[0], w) for w in ws[1:])
+    assert np.abs(ws[0] - ref.get_weights()).max() < 1e-13
