@@ -49,6 +49,19 @@ __device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// Fragment of a 16x16x32 bf16 MFMA from a k-major LDS image img[k][c] (row stride ldt elements, 32*odd bytes):
+// the 16 columns c0..c0+15 of the 32-wide k block at kk, k dealt to the lane groups as described above.
+// ds_read_b64_tr_b16: lane 4q + p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block and
+// receives column (lane & 15) of its four rows.  EXEC must be all ones (every lane of the wave executes this).
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16 *img, int ldt, int c0, int kk, int lane) {
+    const int fr = lane & 15, fg = lane >> 4;
+    const __bf16 *q = img + (kk + 4 * fg + (fr >> 2)) * ldt + c0 + 4 * (fr & 3);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q + 16 * ldt));
+    return join8(lo, hi);
+}
+
 // K depth of one staged tile.  A 4-wave workgroup keeps TWO tiles ahead in registers while it multiplies the
 // staged one (the loads of tile t+2 are issued before tile t is multiplied); with one workgroup per CU (grids
 // of 256..511 tiles) that is all the CU has in flight, and it must cover a memory round trip (~1 500 cycles
@@ -142,14 +155,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
         const __bf16 *q = img + (r0 + fr) * LDK + kk + 4 * fg;
         return join8(*reinterpret_cast<const s16x4 *>(q), *reinterpret_cast<const s16x4 *>(q + 16));
     };
-    auto frag_tr = [&](const __bf16 *img, int ldt, int c0, int kk) {
-        // lane 4q + p of a 16-lane group addresses row q, columns 4p..4p+3 of the 4 x 16 block; it receives column (lane & 15)
-        const __bf16 *q = img + (kk + 4 * fg + (fr >> 2)) * ldt + c0 + 4 * (fr & 3);
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q + 16 * ldt));
-        return join8(lo, hi);
-    };
+    auto frag_tr = [&](const __bf16 *img, int ldt, int c0, int kk) { return tr_frag(img, ldt, c0, kk, lane); };
 
     auto multiply = [&](int k0) {
         const int kmax = (p.K - k0 < BK) ? p.K - k0 : BK; // K is a multiple of 16; rows past it were staged as zeros

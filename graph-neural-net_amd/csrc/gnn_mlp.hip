@@ -87,6 +87,7 @@ struct gnn_mlp {
     Mid4Params mid4p{};
     size_t mid4_lds_bytes = 0;
     const void *mid4_fn[3] = {nullptr, nullptr, nullptr}; // forward only / forward + backward / the same with A_1 from K slabs
+                                                          // (bf16 nets: only slot 2, the bf16 training kernel)
     hipFunction_t mid4_jit[3] = {nullptr, nullptr, nullptr}; // run-time instantiation (jit.h), preferred when set
 
     // two-launch step (tile_step_kernel.h): the tile kernel of step s also makes the first-layer K slabs of step s+1
@@ -432,9 +433,17 @@ void plan_fused(gnn_mlp *h) {
     h->mid4 = false;
     h->mid_generic = false;
     if (h->env_path == 1) return;
-    if (h->dtype != GNN_DTYPE_F32) return; // bf16 operands: generic per-layer GEMMs (gemm_bf16.h)
     const int L = h->L, Lm = L - 1;
     if (L < 3 || L > MAX_LAYERS) return;
+    if (h->dtype != GNN_DTYPE_F32) {
+        // bf16 operands: per-layer GEMMs (gemm_bf16.h) for inference and for nets off the row-block path; training
+        // of a net that fits the row-block kernel takes the two-launch path in bf16 (tile_step_bf16_kernel + the bf16
+        // instance of middle4_kernel)
+        plan_mid4(h);
+        if (h->mid4) plan_chain(h);
+        if (!h->chain) h->mid4 = false;
+        return;
+    }
     // gradient tiles: every layer's 32x32 tiles in one grid (shared by both middle kernels)
     {
         GradParams &g = h->grad;
@@ -477,7 +486,8 @@ void plan_fused(gnn_mlp *h) {
 // kernel table: [shape policy][activation][output kind][backward]
 // variant: 0 forward only, 1 forward + backward, 2 forward + backward with A_1 from the K slabs of tile_step_kernel
 template <class SH, int OUTK> const void *mid4_fn_sh(int act, int variant) {
-#define GNN_M4(A) (variant == 2 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true, false, true>)  \
+#define GNN_M4(A) (variant == 3 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true, false, true, true>) \
+                   : variant == 2 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true, false, true>)  \
                    : variant == 1 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true>)             \
                                   : reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, false>))
     switch (act) {
@@ -507,7 +517,8 @@ const void *mid4_function(const gnn_mlp *h, int variant) {
         if (shape_matches<ShapeMnistB>(h)) return mid4_fn_sh<ShapeMnistB, 0>(h->inner_act, variant);
     }
     // runtime extents: layer count templated (3..6, else generic), activation read from the arguments
-#define GNN_M4RO(NL, OK) (variant == 2 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true, false, true>) \
+#define GNN_M4RO(NL, OK) (variant == 3 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true, false, true, true>) \
+                          : variant == 2 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true, false, true>) \
                           : variant == 1 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true>)           \
                                          : reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, false>))
 #define GNN_M4R(NL) (h->out_kind == GNN_OUT_SOFTMAX_CE ? GNN_M4RO(NL, 0) : GNN_M4RO(NL, 1))
@@ -528,11 +539,16 @@ void plan_mid4(gnn_mlp *h) {
     const int L = h->L, Lm = L - 1;
     Mid4Params &m = h->mid4p;
     m = Mid4Params{};
-    m.plan = make_mid4_plan(h->dims.data(), L);
+    const bool bf16 = h->dtype == GNN_DTYPE_BF16;
+    m.plan = make_mid4_plan(h->dims.data(), L, bf16);
     if (!m.plan.ok) return;
     h->mid4_lds_bytes = (size_t)m.plan.lds_floats * sizeof(float);
     for (int l = 1; l < Lm; l++) { m.W[l] = h->W + h->w_off[l]; m.act[l] = h->act[l]; }
     for (int l = 1; l <= Lm; l++) m.delta[l] = h->delta[l];
+    if (bf16) {
+        for (int l = 1; l < Lm; l++) { m.Wb[l] = h->Wb + h->w_off[l]; m.actb[l] = h->actb[l]; }
+        for (int l = 1; l <= Lm; l++) m.deltab[l] = h->deltab[l];
+    }
     m.last_act = h->last_act;
     m.inner_act = h->inner_act;
     {
@@ -540,8 +556,8 @@ void plan_mid4(gnn_mlp *h) {
         h->specialization = (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE &&
                              (shape_matches<ShapeMnistA>(h) || shape_matches<ShapeMnistB>(h))) ? 1 : 0;
     }
-    for (int bwd = 0; bwd < 3; bwd++) {
-        h->mid4_fn[bwd] = mid4_function(h, bwd);
+    for (int bwd = (bf16 ? 2 : 0); bwd < 3; bwd++) {
+        h->mid4_fn[bwd] = mid4_function(h, (bf16 && bwd == 2) ? 3 : bwd);
         if (hipFuncSetAttribute(h->mid4_fn[bwd], hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)h->mid4_lds_bytes) != hipSuccess) {
             (void)hipGetLastError();
@@ -556,7 +572,7 @@ void plan_mid4(gnn_mlp *h) {
 // batch's first-layer K slabs).  Needs the row-block kernel (middle4) and at most MID4_MAX_SLABS slabs.
 void plan_chain(gnn_mlp *h) {
     h->chain = false;
-    if (h->env_chain_off || !h->mid4 || h->dtype != GNN_DTYPE_F32) return;
+    if (h->env_chain_off || !h->mid4) return;
     const int L = h->L;
     h->n_slabs = (h->ld[0] + TS_TM - 1) / TS_TM;
     if (h->n_slabs > MID4_MAX_SLABS) return;
@@ -570,6 +586,7 @@ void plan_chain(gnn_mlp *h) {
         gl.D = h->delta[l + 1]; gl.ldd = h->ld[l + 1];
         gl.W = h->W + h->w_off[l]; gl.V = h->V + h->w_off[l]; gl.G = h->G + h->w_off[l];
         gl.M = h->ld[l]; gl.N = h->ld[l + 1];
+        if (h->dtype == GNN_DTYPE_BF16) { t.Ab[l] = h->actb[l]; t.Db[l] = h->deltab[l + 1]; t.Wb[l] = h->Wb + h->w_off[l]; }
         gl.tiling = make_xcd_tiling((gl.M + TS_TM - 1) / TS_TM, gl.N / TS_TN);
         gl.block_begin = tiles;
         tiles += gl.tiling.blocks();
@@ -589,7 +606,8 @@ void try_specialize(gnn_mlp *h) {
     if (!h->mid4 || h->specialization != 0 || h->jit_tried) return;
     h->jit_tried = true;
     if (h->env_jit_off) return;
-    const jit::Specialised *sp = jit::get_middle4(h->device, h->dims.data(), h->L, h->inner_act, h->out_kind, h->chain, h->mid4_lds_bytes);
+    const jit::Specialised *sp = jit::get_middle4(h->device, h->dims.data(), h->L, h->inner_act, h->out_kind, h->chain,
+                                                  h->dtype == GNN_DTYPE_BF16, h->mid4_lds_bytes);
     if (!sp) return;
     h->mid4_jit[0] = sp->fn[0];
     h->mid4_jit[1] = sp->fn[1];
@@ -698,6 +716,7 @@ void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float
 
 // ---- tile_step_kernel launches ------------------------------------------------------------------
 struct NextBatch { const float *a0; const int32_t *idx; int B; };
+const __bf16 *a0_bf16(const gnn_mlp *h, const float *a0);
 
 // gsrc / gdst / fwd as in tile_step_kernel.h; fwd_only_layer0: the grid covers layer 0's tiles only
 void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, const float *a0, int B, float step_over_b, float momentum) {
@@ -713,6 +732,17 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
     const dim3 grid(fwd_only ? h->ts_tiles0 : h->ts_tiles), block(TS_THREADS);
     if (fwd_only) t.n_layers = 1;
     const int cls = fwd_only ? GNN_K_FWD_GEMM0 : GNN_K_GRAD_GEMM0;
+    if (h->dtype == GNN_DTYPE_BF16) {
+        if (a0) t.Ab[0] = a0_bf16(h, a0);
+        if (fwd) t.Anb = a0_bf16(h, next->a0);
+        if (fwd_only) launch_timed(h, cls, tile_step_bf16_kernel<0, 0, true>, grid, block, 0, t);
+        else if (gsrc == 1 && gdst == 1) launch_timed(h, cls, tile_step_bf16_kernel<1, 1, false>, grid, block, 0, t);
+        else if (gsrc == 1 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_bf16_kernel<1, 2, false>, grid, block, 0, t);
+        else if (gsrc == 1 && gdst == 2 && fwd) launch_timed(h, cls, tile_step_bf16_kernel<1, 2, true>, grid, block, 0, t);
+        else if (gsrc == 2 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_bf16_kernel<2, 2, false>, grid, block, 0, t);
+        else launch_timed(h, cls, tile_step_bf16_kernel<2, 2, true>, grid, block, 0, t);
+        return;
+    }
     if (fwd_only) launch_timed(h, cls, tile_step_kernel<0, 0, true>, grid, block, 0, t);
     else if (gsrc == 1 && gdst == 1) launch_timed(h, cls, tile_step_kernel<1, 1, false>, grid, block, 0, t);
     else if (gsrc == 1 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_kernel<1, 2, false>, grid, block, 0, t);

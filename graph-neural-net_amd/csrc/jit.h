@@ -42,14 +42,15 @@ inline std::string shape_list(const int *dims, int L) {
 // Compiles middle4_kernel<StaticShape<dims...>, act, outk, backward, false, slabs> for gfx950:
 // (false, false), (true, false) and, when `with_slabs`, (true, true).
 // Returns the code object (empty on failure; *log holds the compiler output).
-inline std::vector<char> compile_middle4(const int *dims, int L, int act, int outk, bool with_slabs, std::string names[3], std::string *log) {
+// bf16: ONE kernel, (true, true, BF16 = true) -- the training kernel of the two-launch path in GNN_DTYPE_BF16 -- in slot 2.
+inline std::vector<char> compile_middle4(const int *dims, int L, int act, int outk, bool with_slabs, bool bf16, std::string names[3], std::string *log) {
     std::vector<char> code;
     const std::string shape = "gnn::StaticShape<" + shape_list(dims, L) + ">";
-    const int n_fn = with_slabs ? 3 : 2;
+    const int n_fn = with_slabs ? 3 : 2, b_first = bf16 ? 2 : 0;
     std::string expr[3];
-    for (int b = 0; b < n_fn; b++)
+    for (int b = b_first; b < n_fn; b++)
         expr[b] = "gnn::middle4_kernel<" + shape + ", " + std::to_string(act) + ", " + std::to_string(outk) + ", " +
-                  (b ? "true" : "false") + ", false, " + (b == 2 ? "true" : "false") + ">";
+                  (b ? "true" : "false") + ", false, " + (b == 2 ? "true" : "false") + ", " + (bf16 ? "true" : "false") + ">";
     const std::string src = "#include \"middle4_kernel.h\"\n";
     const char *hdr_src[] = {kEmbedded_kernels_h, kEmbedded_fused_kernels_h, kEmbedded_middle4_kernel_h};
     const char *hdr_name[] = {"kernels.h", "fused_kernels.h", "middle4_kernel.h"};
@@ -58,7 +59,7 @@ inline std::vector<char> compile_middle4(const int *dims, int L, int act, int ou
         if (log) *log = "hiprtcCreateProgram failed";
         return code;
     }
-    for (int b = 0; b < n_fn; b++) (void)hiprtcAddNameExpression(prog, expr[b].c_str());
+    for (int b = b_first; b < n_fn; b++) (void)hiprtcAddNameExpression(prog, expr[b].c_str());
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
     const hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
     size_t ls = 0;
@@ -68,7 +69,7 @@ inline std::vector<char> compile_middle4(const int *dims, int L, int act, int ou
     }
     if (rc == HIPRTC_SUCCESS) {
         bool ok = true;
-        for (int b = 0; b < n_fn && ok; b++) {
+        for (int b = b_first; b < n_fn && ok; b++) {
             const char *low = nullptr;
             ok = hiprtcGetLoweredName(prog, expr[b].c_str(), &low) == HIPRTC_SUCCESS && low;
             if (ok) names[b] = low;
@@ -85,21 +86,22 @@ inline std::vector<char> compile_middle4(const int *dims, int L, int act, int ou
 
 // Loads (compiling on first use per process) the specialisation for this net on the current
 // device.  One module per (device, shape, act, outk), kept for the life of the process.
-inline const Specialised *get_middle4(int device, const int *dims, int L, int act, int outk, bool with_slabs, size_t lds_bytes) {
+inline const Specialised *get_middle4(int device, const int *dims, int L, int act, int outk, bool with_slabs, bool bf16, size_t lds_bytes) {
+    if (bf16 && !with_slabs) return nullptr;
     static std::mutex mu;
     static std::map<std::string, Specialised> cache;
     const std::string key = std::to_string(device) + "|" + shape_list(dims, L) + "|" + std::to_string(act) + "|" + std::to_string(outk) +
-                            (with_slabs ? "|s" : "");
+                            (with_slabs ? "|s" : "") + (bf16 ? "|bf16" : "");
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
-    if (it != cache.end()) return it->second.fn[1] ? &it->second : nullptr;
+    if (it != cache.end()) return (it->second.fn[1] || it->second.fn[2]) ? &it->second : nullptr;
     Specialised &sp = cache[key];
     std::string names[3];
     sp.n_fn = with_slabs ? 3 : 2;
-    const std::vector<char> code = compile_middle4(dims, L, act, outk, with_slabs, names, &sp.log);
+    const std::vector<char> code = compile_middle4(dims, L, act, outk, with_slabs, bf16, names, &sp.log);
     if (code.empty()) return nullptr;
     if (hipModuleLoadData(&sp.module, code.data()) != hipSuccess) { (void)hipGetLastError(); sp.log += "\nhipModuleLoadData failed"; return nullptr; }
-    for (int b = 0; b < sp.n_fn; b++) {
+    for (int b = (bf16 ? 2 : 0); b < sp.n_fn; b++) {
         if (hipModuleGetFunction(&sp.fn[b], sp.module, names[b].c_str()) != hipSuccess) {
             (void)hipGetLastError();
             sp.fn[0] = sp.fn[1] = sp.fn[2] = nullptr;

@@ -51,13 +51,18 @@ struct Mid4Plan {
     // slabs g, g + sgrp, ..), the group sums meet in the scratch area: every thread has loads in flight
     int ns, sgrp;
     unsigned inv_e;          // ceil(2^22 / ld[1])
+    // BF16 kernels: f'(a_1) image [4][ld[1]+4] (for l >= 2 the f' image shares the slot of delta_l, which is free until
+    // the backward pass writes it), and the staging of the bf16 weight shadow: c8 = ceil(kr[l+1]/8) 16-B pieces per row
+    int off_fp1;
+    int st8_rpt[MAX_LAYERS], st8_trips[MAX_LAYERS], st8_begin[MAX_LAYERS], st8_total;
+    unsigned st8_inv_c8[MAX_LAYERS];
     int lds_floats;          // total dynamic LDS, floats
     bool ok;
 };
 
 __host__ __device__ constexpr int mid4_min(int a, int b) { return a < b ? a : b; }
 
-__host__ __device__ constexpr Mid4Plan make_mid4_plan(const int *dims, int L) {
+__host__ __device__ constexpr Mid4Plan make_mid4_plan(const int *dims, int L, bool bf16 = false) {
     Mid4Plan m{};
     m.L = L;
     m.ok = false;
@@ -81,6 +86,8 @@ __host__ __device__ constexpr Mid4Plan make_mid4_plan(const int *dims, int L) {
     m.off_logits = off; off += 4 * (m.ld[Lm] + 4);
     for (int l = 2; l <= Lm; l++) { m.off_dl[l] = off; off += 4 * (m.ld[l] + 4); }
     m.off_y = off; off += 4 * m.ld[Lm];
+    m.off_fp1 = off;
+    if (bf16) off += 4 * (m.ld[1] + 4);
     m.off_scratch = off;
     m.st_total = 0;
     for (int l = 1; l < Lm; l++) {
@@ -91,6 +98,15 @@ __host__ __device__ constexpr Mid4Plan make_mid4_plan(const int *dims, int L) {
         m.st_begin[l] = m.st_total;
         m.st_total += m.st_trips[l];
         m.st_inv_c4[l] = ((1u << 22) + c4 - 1) / c4;
+    }
+    m.st8_total = 0;
+    for (int l = 1; l < Lm; l++) {
+        const int c8 = (m.kr[l + 1] + 7) / 8; // (the image row has room for the up to 4 extra zero columns: lw >= kr + 4)
+        m.st8_rpt[l] = 1024 / c8;
+        m.st8_trips[l] = (m.kr[l] + m.st8_rpt[l] - 1) / m.st8_rpt[l];
+        m.st8_begin[l] = m.st8_total;
+        m.st8_total += m.st8_trips[l];
+        m.st8_inv_c8[l] = ((1u << 22) + c8 - 1) / c8;
     }
     const int budget = (160 * 1024) / 4 - 64 - off; // floats left for the K-split partials
     if (budget <= 0) return m;
@@ -134,7 +150,17 @@ struct Mid4Params {
     // SLABS kernels: A_1 = f(sum of the K slabs of the first-layer sums) instead of reading act[1];
     // slab s of batch row b at slabs[(s * slab_rows + b) * ld[1]] (tile_step_kernel.h)
     const float *slabs; int slab_rows; int n_slabs;
+    // BF16 kernels: the bf16 shadow of W_l (l = 1..L-2) and the bf16 outputs the tile kernel reads (same lds as the f32 ones)
+    const __bf16 *Wb[MAX_LAYERS];
+    __bf16 *actb[MAX_LAYERS];   // l = 1..L-2
+    __bf16 *deltab[MAX_LAYERS]; // l = 1..L-1
 };
+
+typedef __bf16 m4_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 m4_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned m4_u32x4 __attribute__((ext_vector_type(4)));
+// x rounded to bf16 (nearest even) and widened again: the value a bf16 GEMM operand carries
+__device__ __forceinline__ float bf16_value(float x) { return (float)(__bf16)x; }
 
 constexpr int MID4_MAX_SLABS = 16;
 
@@ -148,9 +174,9 @@ template <int... DIMS> struct StaticShape {
     static constexpr bool is_static = true;
     static constexpr int kL = (int)sizeof...(DIMS);
     static constexpr int kDims[sizeof...(DIMS)] = {DIMS...};
-    __host__ __device__ static constexpr Mid4Plan make() {
+    template <bool BF = false> __host__ __device__ static constexpr Mid4Plan make() {
         constexpr int dims[sizeof...(DIMS)] = {DIMS...};
-        return make_mid4_plan(dims, (int)sizeof...(DIMS));
+        return make_mid4_plan(dims, (int)sizeof...(DIMS), BF);
     }
 };
 
@@ -256,9 +282,16 @@ __device__ __forceinline__ void rowblock_product(const float *A_img, int lda, co
 
 // NSLOT > 0: static shape, the number of weight slabs (Mid4Plan::st_total); 0: runtime extents
 // NS: 0 = A_1 is read from act[1]; > 0 = that many first-layer K slabs (static shape); < 0 = p.n_slabs of them
-template <int NL, int ACT_T, int OUTK, bool BACKWARD, bool STAMP, int NSLOT, int NS>
+// BF: GNN_DTYPE_BF16 -- every operand of the row-block products carries a bf16 value: the weights are staged from
+// the bf16 shadow (half the bytes of the kernel's dominant load) and widened into the same f32 LDS image, activations
+// and deltas are rounded when they are written to their operand images (f' is kept from the unrounded activation),
+// and the products run on the same exact-f32 MFMA -- a product of two bf16 values is exact in f32, so this IS bf16
+// operands with f32 accumulation; the kernel is bound by issue and loads, not by the MFMA rate.  Outputs for the
+// tile kernel (A_l, delta_l) are written as bf16.  NSLOT8: static weight slabs of the bf16 staging.
+template <int NL, int ACT_T, int OUTK, bool BACKWARD, bool STAMP, int NSLOT, int NS, bool BF = false, int NSLOT8 = 0>
 __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     const int ACT = (ACT_T >= 0) ? ACT_T : p.inner_act;
+    auto opv = [](float x) { return BF ? bf16_value(x) : x; };  // the value an operand image holds
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT_ = 1024;
     const int t = threadIdx.x, lane = t & 63;
@@ -316,7 +349,18 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                 const bool lrow = row0 + a1_r < p.B;
 #pragma unroll
                 for (int j = 0; j < 4; j++) a1v[j] = (lrow && a1_q * 4 + j < m.d[1]) ? act_fn(ACT, z[j]) : 0.f;
-                if (a1_on) *reinterpret_cast<f32x4 *>(p.act[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) = a1v; // the gradient kernel reads A_1
+                if (BF) {
+                    f32x4 fp;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { fp[j] = act_prime_from_a(ACT, a1v[j]); a1v[j] = bf16_value(a1v[j]); }
+                    if (a1_on) {
+                        *reinterpret_cast<f32x4 *>(smem + m.off_fp1 + a1_r * (m.ld[1] + 4) + a1_q * 4) = fp;
+                        *reinterpret_cast<m4_bf16x4 *>(p.actb[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) =
+                            (m4_bf16x4){(__bf16)a1v[0], (__bf16)a1v[1], (__bf16)a1v[2], (__bf16)a1v[3]};
+                    }
+                } else if (a1_on) {
+                    *reinterpret_cast<f32x4 *>(p.act[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) = a1v; // the gradient kernel reads A_1
+                }
             }
         }
     };
@@ -331,7 +375,104 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     // The four blocks that share an XCD start at different quarters of the slab sequence.
     {
         const int q = (blockIdx.x >> 3) & 3; // wave-uniform
-        if constexpr (NSLOT > 0) {
+        if constexpr (BF) {
+            // bf16 shadow: rows of c8 = ceil(kr/8) 16-B pieces (8 weights), widened to f32 into the same [k][lw] image
+            auto widen_store = [&](float *dst, m4_bf16x8 w) {
+                const m4_u32x4 u = __builtin_bit_cast(m4_u32x4, w);
+                f32x4 lo, hi;
+                lo[0] = __builtin_bit_cast(float, u[0] << 16); lo[1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+                lo[2] = __builtin_bit_cast(float, u[1] << 16); lo[3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+                hi[0] = __builtin_bit_cast(float, u[2] << 16); hi[1] = __builtin_bit_cast(float, u[2] & 0xffff0000u);
+                hi[2] = __builtin_bit_cast(float, u[3] << 16); hi[3] = __builtin_bit_cast(float, u[3] & 0xffff0000u);
+                *reinterpret_cast<f32x4 *>(dst) = lo;
+                *reinterpret_cast<f32x4 *>(dst + 4) = hi;
+            };
+            constexpr int NV = NSLOT8 > 0 ? NSLOT8 : 10; // static: every slab of every layer in flight; runtime: up to 10 per batch
+            m4_bf16x8 v[NV];
+            bool rows_done = false;
+            auto rows_to_lds = [&]() {
+                if (rows_done) return;
+                rows_done = true;
+                asm volatile("" : "+v"(a1v), "+v"(yv));
+                finish_a1();
+                if (a1_on && sg == 1) *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
+                if (y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv;
+            };
+            if constexpr (NSLOT8 > 0) {
+#pragma unroll
+                for (int j = 1; j < MAX_LAYERS - 1; j++) {
+                    if (j < Lm) {
+                        const int c8 = (m.kr[j + 1] + 7) >> 3, rpt = m.st8_rpt[j], trips = m.st8_trips[j];
+                        const int r0 = t / c8, c = t - r0 * c8;
+                        const unsigned goff = (unsigned)(r0 * m.ld[j + 1] + 8 * c);
+                        const int first = (trips * q) >> 2;
+#pragma unroll
+                        for (int i = 0; i < NSLOT8; i++) {
+                            if (i < trips) {
+                                int tr = i + first;
+                                tr = tr >= trips ? tr - trips : tr;
+                                const int rs = tr * rpt;
+                                const bool ok = r0 < rpt && r0 + rs < m.kr[j];
+                                v[m.st8_begin[j] + i] = *reinterpret_cast<const m4_bf16x8 *>(p.Wb[j] + (ok ? (unsigned)(rs * m.ld[j + 1]) + goff : 0u));
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NSLOT8; i++) asm volatile("" : "+v"(v[i]));
+                rows_to_lds();
+#pragma unroll
+                for (int j = 1; j < MAX_LAYERS - 1; j++) {
+                    if (j < Lm) {
+                        const int c8 = (m.kr[j + 1] + 7) >> 3, rpt = m.st8_rpt[j], trips = m.st8_trips[j];
+                        const int r0 = t / c8, c = t - r0 * c8;
+                        float *dst = smem + m.off_w[j] + r0 * m.lw[j] + 8 * c;
+                        const int first = (trips * q) >> 2;
+#pragma unroll
+                        for (int i = 0; i < NSLOT8; i++) {
+                            if (i < trips) {
+                                int tr = i + first;
+                                tr = tr >= trips ? tr - trips : tr;
+                                const int rs = tr * rpt;
+                                if (r0 < rpt && r0 + rs < m.kr[j]) widen_store(dst + rs * m.lw[j], v[m.st8_begin[j] + i]);
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 1; j < MAX_LAYERS - 1; j++) {
+                    if (j < Lm) {
+                        const int c8 = (m.kr[j + 1] + 7) >> 3, rpt = m.st8_rpt[j], trips = m.st8_trips[j];
+                        const int r0 = (int)(((unsigned)t * m.st8_inv_c8[j]) >> 22), c = t - r0 * c8;
+                        const unsigned goff = (unsigned)(r0 * m.ld[j + 1] + 8 * c);
+                        float *dst = smem + m.off_w[j] + r0 * m.lw[j] + 8 * c;
+                        const int first = (trips * q) >> 2;
+                        for (int tb = 0; tb < trips; tb += NV) {
+#pragma unroll
+                            for (int i = 0; i < NV; i++) {
+                                int tr = tb + i + first;
+                                tr = tr >= trips ? tr - trips : tr;
+                                const int rs = tr * rpt;
+                                const bool ok = tb + i < trips && r0 < rpt && r0 + rs < m.kr[j];
+                                v[i] = *reinterpret_cast<const m4_bf16x8 *>(p.Wb[j] + (ok ? (unsigned)(rs * m.ld[j + 1]) + goff : 0u));
+                            }
+#pragma unroll
+                            for (int i = 0; i < NV; i++) asm volatile("" : "+v"(v[i]));
+                            rows_to_lds(); // the first weight loads are in flight: now the rows
+#pragma unroll
+                            for (int i = 0; i < NV; i++) {
+                                int tr = tb + i + first;
+                                tr = tr >= trips ? tr - trips : tr;
+                                const int rs = tr * rpt;
+                                if (tb + i < trips && r0 < rpt && r0 + rs < m.kr[j]) widen_store(dst + rs * m.lw[j], v[i]);
+                            }
+                        }
+                    }
+                }
+                rows_to_lds();
+            }
+        } else if constexpr (NSLOT > 0) {
             // static shape: every load of every layer in flight before the first LDS write
             f32x4 v[NSLOT];
 #pragma unroll
@@ -431,8 +572,17 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
             const bool lrow = row0 + a1_r < p.B;
 #pragma unroll
             for (int j = 0; j < 4; j++) a1v[j] = (lrow && a1_q * 4 + j < m.d[1]) ? act_fn(ACT, z[j]) : 0.f;
+            if (BF) {
+                f32x4 fp;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { fp[j] = act_prime_from_a(ACT, a1v[j]); a1v[j] = bf16_value(a1v[j]); }
+                *reinterpret_cast<f32x4 *>(smem + m.off_fp1 + a1_r * (m.ld[1] + 4) + a1_q * 4) = fp;
+                *reinterpret_cast<m4_bf16x4 *>(p.actb[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) =
+                    (m4_bf16x4){(__bf16)a1v[0], (__bf16)a1v[1], (__bf16)a1v[2], (__bf16)a1v[3]};
+            } else {
+                *reinterpret_cast<f32x4 *>(p.act[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) = a1v; // the gradient kernel reads A_1
+            }
             *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a1v;
-            *reinterpret_cast<f32x4 *>(p.act[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) = a1v; // the gradient kernel reads A_1
         }
         __syncthreads();
     }
@@ -470,8 +620,16 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                 const bool lrow = row0 + er < p.B;
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = (lrow && n + j < m.d[l]) ? act_fn(ACT, v[j]) : 0.f;
+                if (BF) { // f'(a_l) parks in delta_l's image until the backward pass overwrites it with delta_l
+                    f32x4 fp;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { fp[j] = act_prime_from_a(ACT, v[j]); v[j] = bf16_value(v[j]); }
+                    *reinterpret_cast<f32x4 *>(smem + m.off_dl[l] + er * (N + 4) + n) = fp;
+                    *reinterpret_cast<m4_bf16x4 *>(p.actb[l] + (size_t)(row0 + er) * N + n) = (m4_bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                } else {
+                    *reinterpret_cast<f32x4 *>(p.act[l] + (size_t)(row0 + er) * N + n) = v;
+                }
                 *reinterpret_cast<f32x4 *>(smem + m.off_act[l] + er * (N + 4) + n) = v;
-                *reinterpret_cast<f32x4 *>(p.act[l] + (size_t)(row0 + er) * N + n) = v;
             }
             __syncthreads();
         }
@@ -542,8 +700,11 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
             float *dlast = smem + m.off_dl[Lm] + r * (16 + 4);
             if (ks == 0) {
                 if (p.prob) p.prob[(size_t)row * 16 + c] = out;
-                dlast[c] = dd;
-                if (BACKWARD) p.delta[Lm][(size_t)row * 16 + c] = dd;
+                dlast[c] = opv(dd);
+                if (BACKWARD) {
+                    if (BF) p.deltab[Lm][(size_t)row * 16 + c] = (__bf16)dd;
+                    else p.delta[Lm][(size_t)row * 16 + c] = dd;
+                }
             }
             if (p.loss) {
                 const float lsum = row16_sum(lterm);
@@ -571,9 +732,13 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                                 }
                             }
                         }
-                        const float v = (row < p.B && n < m.d[Lm - 1]) ? acc * act_prime_from_a(ACT, a[n]) : 0.f;
-                        if (Lm - 1 > 1) smem[m.off_dl[Lm - 1] + r * (ldp + 4) + n] = v;
-                        p.delta[Lm - 1][(size_t)row * ldp + n] = v;
+                        // (BF: f' of the unrounded activation was parked by the forward pass -- in delta_{L-2}'s own slot, or
+                        //  in the f'(a_1) image when layer L-2 is layer 1)
+                        const float fpv = BF ? smem[((Lm - 1 > 1) ? m.off_dl[Lm - 1] : m.off_fp1) + r * (ldp + 4) + n] : act_prime_from_a(ACT, a[n]);
+                        const float v = (row < p.B && n < m.d[Lm - 1]) ? acc * fpv : 0.f;
+                        if (Lm - 1 > 1) smem[m.off_dl[Lm - 1] + r * (ldp + 4) + n] = opv(v);
+                        if (BF) p.deltab[Lm - 1][(size_t)row * ldp + n] = (__bf16)v;
+                        else p.delta[Lm - 1][(size_t)row * ldp + n] = v;
                     }
                 }
             }
@@ -607,8 +772,11 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
         const float yy = (live && p.Y) ? smem[m.off_y + mr * 16 + c0] : 0.f;
         const float dd = live ? pr - yy : 0.f;                       // SCE:250
         if (p.prob) p.prob[(size_t)row * 16 + c0] = pr;
-        smem[m.off_dl[Lm] + mr * (16 + 4) + c0] = dd;
-        if (BACKWARD) p.delta[Lm][(size_t)row * 16 + c0] = dd;
+        smem[m.off_dl[Lm] + mr * (16 + 4) + c0] = opv(dd);
+        if (BACKWARD) {
+            if (BF) p.deltab[Lm][(size_t)row * 16 + c0] = (__bf16)dd;
+            else p.delta[Lm][(size_t)row * 16 + c0] = dd;
+        }
         if (p.loss) {
             const float lse = mx + __logf(s);
             const float lsum = row16_sum((live && yy != 0.f) ? yy * (lse - zv) : 0.f); // -y ln p, SCE:216
@@ -651,8 +819,11 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                 const float yy = (live && p.Y) ? y[c] : 0.f;
                 const float dd = live ? pr - yy : 0.f;          // SCE:250
                 if (p.prob) p.prob[(size_t)row * N + c] = pr;
-                dimg[c] = dd;
-                if (BACKWARD) p.delta[Lm][(size_t)row * N + c] = dd;
+                dimg[c] = opv(dd);
+                if (BACKWARD) {
+                    if (BF) p.deltab[Lm][(size_t)row * N + c] = (__bf16)dd;
+                    else p.delta[Lm][(size_t)row * N + c] = dd;
+                }
                 if (live && yy != 0.f) lsum += yy * (lse - z[c]); // -y ln p, SCE:216
             }
         } else {
@@ -663,8 +834,11 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                 const float df = a - yy;
                 const float dd = live ? df * act_prime_from_a(p.last_act, a) : 0.f; // GNN:267-271
                 if (p.prob) p.prob[(size_t)row * N + c] = live ? a : 0.f;
-                dimg[c] = dd;
-                if (BACKWARD) p.delta[Lm][(size_t)row * N + c] = dd;
+                dimg[c] = opv(dd);
+                if (BACKWARD) {
+                    if (BF) p.deltab[Lm][(size_t)row * N + c] = (__bf16)dd;
+                    else p.delta[Lm][(size_t)row * N + c] = dd;
+                }
                 if (live) {
                     lsum += 0.5f * df * df;
                     if (c == 0 && a != a) nan_flag = 1.f;
@@ -706,12 +880,19 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (n < NR)
                     for (int ks = 0; ks < KS; ks++) v += *reinterpret_cast<const f32x4 *>(smem + m.off_scratch + (ks * 4 + er) * gw + n);
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(smem + m.off_act[l] + er * (N + 4) + n);
+                // f'(z_l): from a_l = f(z_l); BF: parked by the forward pass (from the unrounded a_l) in delta_l's slot / the f'(a_1) image
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(smem + (BF ? (l > 1 ? m.off_dl[l] : m.off_fp1) : m.off_act[l]) + er * (N + 4) + n);
                 const bool lrow = row0 + er < p.B;
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = (lrow && n + j < m.d[l]) ? v[j] * act_prime_from_a(ACT, a[j]) : 0.f;
+                for (int j = 0; j < 4; j++) v[j] = (lrow && n + j < m.d[l]) ? v[j] * (BF ? a[j] : act_prime_from_a(ACT, a[j])) : 0.f;
+                if (BF) {
+                    *reinterpret_cast<m4_bf16x4 *>(p.deltab[l] + (size_t)(row0 + er) * N + n) = (m4_bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = bf16_value(v[j]);
+                } else {
+                    *reinterpret_cast<f32x4 *>(p.delta[l] + (size_t)(row0 + er) * N + n) = v;
+                }
                 if (l > 1) *reinterpret_cast<f32x4 *>(smem + m.off_dl[l] + er * (N + 4) + n) = v;
-                *reinterpret_cast<f32x4 *>(p.delta[l] + (size_t)(row0 + er) * N + n) = v;
             }
         }
         __syncthreads();
@@ -722,17 +903,19 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
 }
 
 // SLABS: A_1 comes as K slabs from tile_step_kernel (64 input neurons per slab) instead of from act[1]
-template <class SH, int ACT, int OUTK, bool BACKWARD, bool STAMP = false, bool SLABS = false>
+// BF16 : GNN_DTYPE_BF16 (see middle4_body); built only as the training kernel of the two-launch path (BACKWARD, SLABS)
+template <class SH, int ACT, int OUTK, bool BACKWARD, bool STAMP = false, bool SLABS = false, bool BF16 = false>
 __global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
+    static_assert(!BF16 || (BACKWARD && SLABS), "the bf16 row-block kernel exists for the two-launch training path only");
     if constexpr (SH::is_static) {
         // a LOCAL constexpr object: every member access with a compile-time index folds to an
         // immediate (a namespace-scope constant would be loaded from memory)
-        constexpr Mid4Plan m = SH::make();
+        constexpr Mid4Plan m = SH::template make<BF16>();
         constexpr int ns = SLABS ? (m.ld[0] + 63) / 64 : 0;
         static_assert(ns <= MID4_MAX_SLABS, "too many first-layer slabs for the register-resident sum");
-        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, m.st_total, ns>(m, p);
+        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, m.st_total, ns, BF16, m.st8_total>(m, p);
     } else {
-        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, 0, SLABS ? -1 : 0>(p.plan, p);
+        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, 0, SLABS ? -1 : 0, BF16, 0>(p.plan, p);
     }
 }
 

@@ -31,6 +31,7 @@
 //             slab is stored 16 B per lane from the accumulators (no LDS image, one barrier in all)
 #pragma once
 #include "fused_kernels.h"
+#include "gemm_bf16.h"
 
 namespace gnn {
 
@@ -50,6 +51,9 @@ struct TileStepParams {
     float *slabs;                // [n slabs][slab_rows][ldz]
     int slab_rows, ldz;
     unsigned long long *stamps;  // STAMP builds only (tools/tile_probe.hip): 16 slots per block
+    // GNN_DTYPE_BF16 (tile_step_bf16_kernel): the bf16 roundings of the operands, same shapes and leading dimensions
+    const __bf16 *Ab[MAX_LAYERS]; const __bf16 *Db[MAX_LAYERS]; __bf16 *Wb[MAX_LAYERS];
+    const __bf16 *Anb;
 };
 
 #define GNN_TS_STAMP(i)                                                                                  \
@@ -257,6 +261,158 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     }
     GNN_TS_STAMP(6);
     GNN_TS_STAMP_REAL(9);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile_step_bf16_kernel: the same tile owner with bf16 GEMM operands (GNN_DTYPE_BF16): activations, deltas,
+// next-batch rows and the weight tile enter the two products as bf16 (written once by their producers), both
+// products run on v_mfma_f32_16x16x32_bf16 with f32 accumulation, the update is on the f32 masters and the
+// tile's new weights go back to the bf16 shadow.  128 f32 MFMAs per tile become 16 (gradient) + 16 (forward);
+// the operand images are half the bytes.  Both gradient operands are k-major ([batch row][neuron]): staged as
+// they are and read with ds_read_b64_tr_b16; the weight tile [m][n] is k-major for the forward product too.
+// ------------------------------------------------------------------------------------------------
+template <int GSRC, int GDST, bool FWD>
+__global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepParams p) {
+    constexpr int LDA = TS_TM + 16;  // [k][m] bf16 image: 160-B rows (32*odd)
+    constexpr int LDD = TS_TN;       // [k][n] bf16 image: 32-B rows
+    constexpr int LDW = TS_TN + 4;   // f32 partial tiles [m][n]
+    __shared__ __attribute__((aligned(16))) __bf16 sA[TS_KC * LDA];
+    __shared__ __attribute__((aligned(16))) __bf16 sD[TS_KC * LDD];
+    __shared__ __attribute__((aligned(16))) float sC[2 * TS_TM * LDW];
+    __shared__ __attribute__((aligned(16))) __bf16 sW[TS_TM * TS_TN]; // the tile's (new) weights [m][n], 32-B rows
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_LAYERS; i++)
+        if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].block_begin) li = i;
+    const GradLayer &L = p.layer[li];
+    int tm, tn;
+    if (!L.tiling.tile_of(blockIdx.x - L.block_begin, tm, tn)) return;
+    const int m0 = tm * TS_TM, n0 = tn * TS_TN;
+    const bool fwd = FWD && li == 0;
+    const __bf16 *Ab = p.Ab[li], *Db = p.Db[li];
+
+    const int er = t >> 2, eq = t & 3;
+    const bool e_ok = t < 256 && (m0 + er < L.M);
+    const size_t e_off = (size_t)(m0 + er) * L.ldd + n0 + eq * 4;
+
+    // ---- loads: gradient operands of the first K chunk, the tile's masters, then the next batch's rows ----
+    bf16x8 va[2], vd;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_grad = [&](int k0, int kc) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int idx = t + i * TS_THREADS, k = idx >> 3, q = idx & 7; // 8 chunks of 8 bf16 per row
+            va[i] = zero8;
+            if (k < kc && m0 + q * 8 < L.M) {
+                size_t a_row = (size_t)(k0 + k);
+                bool live = true;
+                if (li == 0 && p.row_idx) { live = k0 + k < p.k_true; a_row = live ? (size_t)p.row_idx[k0 + k] : 0; }
+                if (live) va[i] = *reinterpret_cast<const bf16x8 *>(Ab + a_row * L.lda + m0 + q * 8);
+            }
+        }
+        vd = zero8;
+        if (t < 256) {
+            const int k = t >> 1, q = t & 1;
+            if (k < kc) vd = *reinterpret_cast<const bf16x8 *>(Db + (size_t)(k0 + k) * L.ldd + n0 + q * 8);
+        }
+    };
+    const int kc0 = (p.K < TS_KC) ? p.K : TS_KC;
+    if (GSRC == 1) load_grad(0, kc0);
+    float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f), v_old = w_old, g_in = w_old;
+    if (e_ok) {
+        if (GDST == 2 || FWD) w_old = *reinterpret_cast<const float4 *>(L.W + e_off);
+        if (GDST == 2) v_old = *reinterpret_cast<const float4 *>(L.V + e_off);
+        if (GSRC == 2) g_in = *reinterpret_cast<const float4 *>(L.G + e_off);
+    }
+    // next batch: lane (fr, fg) of wave w -> row 16w + fr; per 32-wide k block the inputs 4fg..4fg+3 and 16+4fg..+3
+    s16x4 vn[2][2];
+    auto load_next = [&](int b0) {
+        const int b = b0 + wave * 16 + fr;
+        const bool live = b < p.next_rows;
+        const size_t row = live ? (p.next_idx ? (size_t)p.next_idx[b] : (size_t)b) : 0;
+        const __bf16 *src = p.Anb + row * p.ldan + m0 + 4 * fg;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                vn[kb][hh] = (s16x4){0, 0, 0, 0};
+                if (live && m0 + kb * 32 + hh * 16 + 4 * fg < L.M) vn[kb][hh] = *reinterpret_cast<const s16x4 *>(src + kb * 32 + hh * 16);
+            }
+    };
+    if (fwd) load_next(0);
+
+    // ---- gradient tile ------------------------------------------------------------------------------
+    float4 g = g_in;
+    if (GSRC == 1) {
+        const int mt = wave & 3, kh = wave >> 2;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < p.K; k0 += TS_KC) {
+            const int kc = (p.K - k0 < TS_KC) ? p.K - k0 : TS_KC;
+            if (k0) { __syncthreads(); load_grad(k0, kc); }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int idx = t + i * TS_THREADS, k = idx >> 3, q = idx & 7;
+                *reinterpret_cast<bf16x8 *>(&sA[k * LDA + q * 8]) = va[i];
+            }
+            if (t < 256) *reinterpret_cast<bf16x8 *>(&sD[(t >> 1) * LDD + (t & 1) * 8]) = vd;
+            __syncthreads();
+            // this wave's half of the chunk's 32-wide k blocks (rows past kc were staged as zeros)
+            for (int kk = kh * 64; kk < kh * 64 + 64; kk += 32) {
+                if (kk >= kc) break;
+                const bf16x8 a = tr_frag(sA, LDA, mt * 16, kk, lane);
+                const bf16x8 b = tr_frag(sD, LDD, 0, kk, lane);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) sC[(kh * TS_TM + mt * 16 + fg * 4 + r) * LDW + fr] = acc[r];
+        __syncthreads();
+        if (t < 256) {
+            const float4 g0 = *reinterpret_cast<const float4 *>(&sC[er * LDW + eq * 4]);
+            const float4 g1 = *reinterpret_cast<const float4 *>(&sC[(TS_TM + er) * LDW + eq * 4]);
+            g = make_float4(g0.x + g1.x, g0.y + g1.y, g0.z + g1.z, g0.w + g1.w);
+        }
+    }
+
+    float4 w_new = w_old;
+    if (GDST == 1) {
+        if (e_ok) *reinterpret_cast<float4 *>(L.G + e_off) = g;
+    } else if (GDST == 2) {
+        float4 adj; // ((step*G)/B) + (momentum*prev), SCE:333, on the f32 masters
+        adj.x = sgd_adj(p.step_over_b, g.x, p.momentum, v_old.x);
+        adj.y = sgd_adj(p.step_over_b, g.y, p.momentum, v_old.y);
+        adj.z = sgd_adj(p.step_over_b, g.z, p.momentum, v_old.z);
+        adj.w = sgd_adj(p.step_over_b, g.w, p.momentum, v_old.w);
+        w_new = make_float4(w_old.x - adj.x, w_old.y - adj.y, w_old.z - adj.z, w_old.w - adj.w);
+        if (e_ok) {
+            *reinterpret_cast<float4 *>(L.W + e_off) = w_new;
+            *reinterpret_cast<float4 *>(L.V + e_off) = adj;
+            *reinterpret_cast<bf16x4 *>(p.Wb[li] + e_off) = (bf16x4){(__bf16)w_new.x, (__bf16)w_new.y, (__bf16)w_new.z, (__bf16)w_new.w};
+        }
+    }
+    if (!fwd) return;
+
+    // ---- next batch's first-layer sums over this tile's 64 inputs, transposed: Zp^T[n][b] = sum_m W[m][n] A'[b][m] ----
+    if (t < 256) {
+        const float4 w = e_ok ? w_new : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<bf16x4 *>(&sW[er * TS_TN + eq * 4]) = (bf16x4){(__bf16)w.x, (__bf16)w.y, (__bf16)w.z, (__bf16)w.w};
+    }
+    __syncthreads();
+    float *slab = p.slabs + (size_t)tm * p.slab_rows * p.ldz;
+    const bf16x8 w0 = tr_frag(sW, TS_TN, 0, 0, lane), w1 = tr_frag(sW, TS_TN, 0, 32, lane); // A operand: rows n, k = m
+    for (int b0 = 0; b0 < p.next_K; b0 += TS_KC) {
+        if (b0) load_next(b0);
+        if (b0 + wave * 16 < p.next_K) { // wave-uniform
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, join8(vn[0][0], vn[0][1]), z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, join8(vn[1][0], vn[1][1]), z, 0, 0, 0);
+            *reinterpret_cast<f32x4 *>(slab + (size_t)(b0 + wave * 16 + fr) * p.ldz + n0 + 4 * fg) = z; // rows n = 4fg + r, column b = fr
+        }
+    }
 }
 
 } // namespace gnn
