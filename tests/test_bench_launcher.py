@@ -32,8 +32,15 @@ def test_launcher_relays_one_line_and_falls_back_to_fresh_eager_ranks(monkeypatc
             return b.EXIT_CAPTURE_FAILED, ""
         return 0, '{"n_gpus": %d}\n' % world
     monkeypatch.setattr(b, "run_group", fake_group)
+    # the driver's call shape: eager ranks, ONE attempt (graph replay on more than one rank is opt-in)
     args = b.parse_args(["--gpus", "4"])
     assert b.launch(args, ["--gpus", "4"]) == 0
+    assert calls == [(4, "eager")]
+    assert capsys.readouterr().out.strip() == '{"n_gpus": 4}'
+    # the test hook: a graph attempt that fails, then fresh ranks in eager mode
+    calls.clear()
+    args = b.parse_args(["--gpus", "4", "--inject-capture-failure"])
+    assert b.launch(args, ["--gpus", "4", "--inject-capture-failure"]) == 0
     assert calls == [(4, "graph"), (4, "eager")]
     assert capsys.readouterr().out.strip() == '{"n_gpus": 4}'
     # an explicit mode is not second-guessed; any other failure is passed through
