@@ -400,7 +400,9 @@ def worker(args, argv):
         is_dp = dist is not None
         names = {"fwd": "fwd_first(128x784x300)", "mid": "middle(fwd L2.. + softmax + bwd-data)",
                  "grad": "grad_update(all layers, 784x300xB + ...%s)" % (", stores G; update after the all-reduce" if is_dp else "")}
-        pmc_key = {"fwd": "fwd_first", "mid": "middle4", "grad": "grad_update"}
+        # kernel names in the PMC file: the two-launch path's kernels first, the three-launch ones as the fallback
+        pmc_key = {"fwd": ["tile_step_kernel<0, 0, true", "fwd_first"], "mid": ["middle4"],
+                   "grad": ["tile_step_kernel<1, 2, true", "grad_update"]}
         kernels = {
             "fwd": (fwd_us, fwd_n, 2.0 * BATCH * DIMS[0] * DIMS[1],
                     eo * (BATCH * DIMS[0] + DIMS[0] * DIMS[1]) + eo * BATCH * DIMS[1]),
@@ -421,7 +423,7 @@ def worker(args, argv):
                     "mfma_frac": round(flop / (us * 1e-6) / 1e12 / mfma_peak, 4),
                     "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                     "share_of_step": round(us * n / (step_us * nt), 3),
-                    "traffic": None if is_dp or bf16 else pmc_traffic(pmc_key[k])}
+                    "traffic": None if is_dp or bf16 else next((v for v in map(pmc_traffic, pmc_key[k]) if v is not None), None)}
         if kernels:
             # roofline kernel = the one with the largest share of the step's time.  Which roof: its
             # arithmetic intensity against the ridge of this dtype (peak FLOP/s / 8 TB/s).
