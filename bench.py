@@ -386,6 +386,7 @@ def worker(args, argv):
         fwd_us, fwd_n = net.timing_read(0)
         grad_us, grad_n = net.timing_read(1)
         mid_us, mid_n = net.timing_read(3)
+        upd_us, upd_n = net.timing_read(4)
         net.timing_enable(False)
         P_all = sum(DIMS[l] * DIMS[l + 1] for l in range(len(DIMS) - 1))
         P_mid = P_all - DIMS[0] * DIMS[1]
@@ -398,19 +399,45 @@ def worker(args, argv):
         #   (data-parallel path: the same kernel stores G instead -- P written, W and V untouched;
         #    the update is sgd_momentum_kernel after the all-reduce)
         is_dp = dist is not None
-        names = {"fwd": "fwd_first(128x784x300)", "mid": "middle(fwd L2.. + softmax + bwd-data)",
-                 "grad": "grad_update(all layers, 784x300xB + ...%s)" % (", stores G; update after the all-reduce" if is_dp else "")}
+        two_launch = net.step_launches == 2      # tile-owner kernel + row-block kernel (csrc/tile_step_kernel.h)
+        f01 = 2.0 * BATCH * DIMS[0] * DIMS[1]     # one 784 x 300 product over the batch
+        if two_launch and not is_dp:
+            # the timed class "grad" is the tile-owner kernel: every layer's gradient + the update + the NEXT batch's
+            # first-layer product; "fwd" is the forward-only launch that opens a chain (once per training call)
+            names = {"fwd": "tile_step<forward only> (first layer of the chain's first batch, 128x784x300)",
+                     "mid": "middle4 (K-slab sum + f, layers 2.., softmax/CE, backward data)",
+                     "grad": "tile_step (G = A^T.delta all layers + momentum update + next batch's 128x784x300)"}
+            kernels = {
+                "fwd": (fwd_us, fwd_n, f01, eo * (BATCH * DIMS[0] + DIMS[0] * DIMS[1]) + 4 * BATCH * DIMS[1]),
+                "mid": (mid_us, mid_n, 2.0 * BATCH * 2 * P_mid,
+                        eo * 2 * P_mid + 4 * BATCH * DIMS[1] + eo * BATCH * 2 * sum(DIMS[1:]) + 4 * BATCH * 2 * DIMS[-1]),
+                "grad": (grad_us, grad_n, 2.0 * BATCH * P_all + f01,
+                         4 * 4 * P_all + (2 * P_all if bf16 else 0) + eo * BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:]))
+                         + eo * BATCH * DIMS[0] + 4 * BATCH * DIMS[1]),
+            }
+            gemm01 = ("grad", 2 * f01)            # both 784 x 300 products of a step run inside this kernel
+        else:
+            names = {"fwd": "first layer (128x784x300)", "mid": "middle(fwd L2.. + softmax + bwd-data)",
+                     "grad": "gradient kernel (all layers, 784x300xB + ...%s)" % (", stores G; update after the all-reduce" if is_dp else " + update")}
+            kernels = {
+                "fwd": (fwd_us, fwd_n, f01, eo * (BATCH * DIMS[0] + DIMS[0] * DIMS[1]) + eo * BATCH * DIMS[1]),
+                "mid": (mid_us, mid_n, 2.0 * BATCH * 2 * P_mid,
+                        eo * 2 * P_mid + eo * BATCH * (DIMS[1] + 2 * sum(DIMS[1:])) + 4 * BATCH * 2 * DIMS[-1]),
+                "grad": (grad_us, grad_n, 2.0 * BATCH * P_all,
+                         4 * (1 if is_dp else 4) * P_all + eo * BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:]))),
+            }
+            gemm01 = ("fwd", f01)
+            if is_dp and upd_n:
+                # data-parallel path: the update after the all-reduce -- by weight tiles with the next batch's first layer
+                # fused in (two-launch path, a next-batch hint given), else the flat momentum kernel
+                names["upd"] = "update after the all-reduce (+ next batch's 128x784x300 on the two-launch path)"
+                kernels["upd"] = (upd_us, upd_n, f01 if two_launch else 0.0,
+                                  4 * 5 * P_all + (eo * BATCH * DIMS[0] + 4 * BATCH * DIMS[1] if two_launch else 0))
+                if two_launch:
+                    gemm01 = ("upd", f01)
         # kernel names in the PMC file: the two-launch path's kernels first, the three-launch ones as the fallback
         pmc_key = {"fwd": ["tile_step_kernel<0, 0, true", "fwd_first"], "mid": ["middle4"],
-                   "grad": ["tile_step_kernel<1, 2, true", "grad_update"]}
-        kernels = {
-            "fwd": (fwd_us, fwd_n, 2.0 * BATCH * DIMS[0] * DIMS[1],
-                    eo * (BATCH * DIMS[0] + DIMS[0] * DIMS[1]) + eo * BATCH * DIMS[1]),
-            "mid": (mid_us, mid_n, 2.0 * BATCH * 2 * P_mid,
-                    eo * 2 * P_mid + eo * BATCH * (DIMS[1] + 2 * sum(DIMS[1:])) + 4 * BATCH * 2 * DIMS[-1]),
-            "grad": (grad_us, grad_n, 2.0 * BATCH * P_all,
-                     4 * (1 if is_dp else 4) * P_all + eo * BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:]))),
-        }
+                   "grad": ["tile_step_kernel<1, 2, true", "grad_update"], "upd": ["tile_step_kernel<2, 2, true", "sgd_momentum"]}
         kernels = {k: v for k, v in kernels.items() if v[1] > 0 and v[0] > 0}
         step_us = dt / K * 1e6
         whole_flop = (6 * P_all - 2 * DIMS[0] * DIMS[1]) * BATCH
@@ -444,7 +471,10 @@ def worker(args, argv):
                         "share_of_step": e["share_of_step"],
                         "limiter": "launch + memory latency and instruction issue, not bandwidth or MFMA rate: the launch moves "
                                    "<1 MB and <0.1 GFLOP (DESIGN.md 3.3)",
-                        "gemm_784x300_mfma_frac": entry("fwd")["mfma_frac"] if "fwd" in kernels else None,
+                        # the north-star GEMM: FLOPs of the 784x300 product(s) / the time of the kernel they run in / MFMA peak
+                        "gemm_784x300_mfma_frac": (round(gemm01[1] / (kernels[gemm01[0]][0] * 1e-6) / 1e12 / mfma_peak, 4)
+                                                   if gemm01[0] in kernels else None),
+                        "gemm_784x300_kernel": names[gemm01[0]] if gemm01[0] in kernels else None,
                         # SURVEY 8d, whole step: 6P - 2 d0 d1 FLOP per sample; bytes = weights (P + (P - d0 d1) + P + 5P)
                         # + activations B (d0 + 4 sum_{l>=1} d_l), 4 B each
                         "whole_step": {"flop": whole_flop, "algorithmic_bytes": whole_bytes, "us": round(step_us, 3),
