@@ -214,10 +214,10 @@ template <class K, class P> void launch_timed(gnn_mlp *h, int cls, K kernel, dim
 }
 
 // ---- GEMM dispatch ----------------------------------------------------------------------
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2>
 void launch_gemm_t(gnn_mlp *h, int cls, const GemmParams &p) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-    launch_timed(h, cls, gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>, grid, dim3(256), 0, p);
+    launch_timed(h, cls, gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, WM>, grid, dim3(WM * 128), 0, p);
 }
 
 // tile edge: keep >= ~256 workgroups in flight where the problem allows it (256 CUs)
@@ -231,8 +231,10 @@ int pick_tile(int M, int N) {
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
     const int tile = pick_tile(p.M, p.N);
-    // A square grid of 256..511 tiles is ONE 4-wave workgroup per CU: nothing covers its barriers and LDS
-    // latencies.  Halving the tile along n puts two workgroups on every CU (config 4: 458 -> 447 us).
+    // A square grid of 256..511 tiles is ONE 4-wave workgroup per CU: nothing covers its barriers and LDS latencies.
+    // Halving the tile along n puts two workgroups on every CU.  (Eight waves on the 64 x 64 tile instead -- WM = 4, two
+    // waves per SIMD from one workgroup and a third less operand traffic -- measured 414 vs 420 us/step on config 4 and
+    // is not used: profiles/r02/f32_gemm_experiments.md.)
     if (tile == 64 && (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64) < 512) { launch_gemm_t<64, 32, A_KC, B_KC, EPI>(h, cls, p); return; }
     switch (tile) {
     case 128: launch_gemm_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;

@@ -92,10 +92,13 @@ struct GemmParams {
     int act;
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+// WM: wave rows (waves are WM x 2, WM * 128 threads).  WM = 4 puts EIGHT waves on a tile -- two per SIMD from one
+// workgroup, which is what covers barriers and LDS latency when the grid has only one workgroup per CU.
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2>
+__global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
+    constexpr int NT = WM * 128;
     constexpr int BK = (BM <= 64) ? 64 : 32;    // small tiles do few MFMAs per wave per 32 k: twice the K per barrier pair
-    constexpr int TM = BM / 32, TN = BN / 32;   // 16x16 MFMA tiles per wave (waves are 2 x 2)
+    constexpr int TM = BM / (WM * 16), TN = BN / 32;   // 16x16 MFMA tiles per wave (waves are WM x 2)
     constexpr int LDAS = BM + 16, LDBS = BN + 16; // row stride = 16 (mod 32) floats: lanes 0-15 / 16-31 hit disjoint banks
     __shared__ __attribute__((aligned(16))) float As[BK * LDAS];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDBS];
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-    constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256; // float4 per thread per tile
-    static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+    constexpr int NA = BM * BK / 4 / NT, NB = BN * BK / 4 / NT; // float4 per thread per tile
+    static_assert(NA >= 1 && NB >= 1 && TM >= 1, "tile too small for this many threads");
     // TWO register stages for tiles up to 64x64: a single tile of prefetch -- ~1000 cycles of MFMAs
     // on a 64x64 tile, 256 on a 32x32 one -- does not cover the >=2000 cycles of memory latency;
     // the loads of tile t+2 are issued before tile t is multiplied
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     auto load_tiles = [&](int k0, float4 (&ra)[NA], float4 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int idx = t + i * 256;
+            const int idx = t + i * NT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (A_KC) {
                 const int m = idx % BM, kq = idx / BM;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int idx = t + i * 256;
+            const int idx = t + i * NT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (B_KC) {
                 const int n = idx % BN, kq = idx / BN;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     auto store_tiles = [&](const float4 (&ra)[NA], const float4 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int idx = t + i * 256;
+            const int idx = t + i * NT;
             if (A_KC) {
                 const int m = idx % BM, kq = idx / BM;
                 As[(kq * 4 + 0) * LDAS + m] = ra[i].x;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int idx = t + i * 256;
+            const int idx = t + i * NT;
             if (B_KC) {
                 const int n = idx % BN, kq = idx / BN;
                 Bs[(kq * 4 + 0) * LDBS + n] = rb[i].x;
@@ -191,29 +194,53 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     typedef float vec_a __attribute__((ext_vector_type(TM == 1 ? 2 : TM))); // (a 1-vector is not a type; b32 read below)
     typedef float vec_b __attribute__((ext_vector_type(TN == 1 ? 2 : TN)));
 
+    // The fragments of k step j+1 are read while the MFMAs of step j issue: with one workgroup per CU (one wave per
+    // SIMD) nothing else covers the ~100 cycles between a ds_read and its first use, and the compiler, left alone,
+    // emits read - wait - 8 MFMAs - read - wait ... (a quarter of the MFMA time exposed on 64 x 64 tiles).
+    auto read_frag = [&](int kk, float (&a)[TM], float (&b)[TN]) {
+        if constexpr (TM == 1) {
+            a[0] = As[kk * LDAS + a_base];
+        } else {
+            const vec_a va = *reinterpret_cast<const vec_a *>(&As[kk * LDAS + a_base]);
+#pragma unroll
+            for (int i = 0; i < TM; i++) a[i] = va[i];
+        }
+        if constexpr (TN == 1) {
+            b[0] = Bs[kk * LDBS + b_base];
+        } else {
+            const vec_b vb = *reinterpret_cast<const vec_b *>(&Bs[kk * LDBS + b_base]);
+#pragma unroll
+            for (int j = 0; j < TN; j++) b[j] = vb[j];
+        }
+    };
     auto multiply = [&]() {
+        // blocks of two k steps; the scheduler is told the order (next block's LDS reads, then this block's MFMAs)
+        float a0[2][TM], b0[2][TN], a1[2][TM], b1[2][TN];
+        read_frag(0, a0[0], b0[0]);
+        read_frag(4, a0[1], b0[1]);
+        auto mfma_block = [&](float (&a)[2][TM], float (&b)[2][TN]) {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
-            float a[TM], b[TN];
-            if constexpr (TM == 1) {
-                a[0] = As[kk * LDAS + a_base];
-            } else {
-                const vec_a va = *reinterpret_cast<const vec_a *>(&As[kk * LDAS + a_base]);
+            for (int u = 0; u < 2; u++)
 #pragma unroll
-                for (int i = 0; i < TM; i++) a[i] = va[i];
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+        };
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            read_frag(kk + 8, a1[0], b1[0]);
+            read_frag(kk + 12, a1[1], b1[1]);
+            mfma_block(a0, b0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);            // the four DS reads of the next block first
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);  // then this block's MFMAs
+            if (kk + 16 < BK) {
+                read_frag(kk + 16, a0[0], b0[0]);
+                read_frag(kk + 20, a0[1], b0[1]);
             }
-            if constexpr (TN == 1) {
-                b[0] = Bs[kk * LDBS + b_base];
-            } else {
-                const vec_b vb = *reinterpret_cast<const vec_b *>(&Bs[kk * LDBS + b_base]);
-#pragma unroll
-                for (int j = 0; j < TN; j++) b[j] = vb[j];
-            }
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            mfma_block(a1, b1);
+            if (kk + 16 < BK) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
         }
     };
     constexpr bool TWO_STAGES = (BM <= 64); // 128x128 tiles: the second stage would cost a wave of occupancy

@@ -60,6 +60,15 @@ int main(int argc, char **argv) {
         CK(hipFuncSetAttribute((const void *)&middle4_kernel<RuntimeShape<4>, 0, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
         CK(hipFuncSetAttribute((const void *)&middle4_kernel<SS, 0, 0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
         CK(hipFuncSetAttribute((const void *)&middle4_kernel<SS, 0, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        CK(hipFuncSetAttribute((const void *)&middle4_kernel<SS, 0, 0, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        CK(hipFuncSetAttribute((const void *)&middle4_kernel<SS, 0, 0, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        // first-layer K slabs (two-launch path): 13 slabs of [Bp][304]
+        const int ns = (ld[0] + 63) / 64;
+        float *slabs; CK(hipMalloc(&slabs, (size_t)ns * Bp * ld[1] * 4));
+        std::vector<float> hsl((size_t)ns * Bp * ld[1]);
+        for (auto &x : hsl) x = (rand() / (float)RAND_MAX - 0.5f) * 0.3f;
+        CK(hipMemcpy(slabs, hsl.data(), hsl.size() * 4, hipMemcpyHostToDevice));
+        m4.slabs = slabs; m4.slab_rows = Bp; m4.n_slabs = ns;
     }
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -86,6 +95,7 @@ int main(int argc, char **argv) {
     time_it("middle4 runtime shape", 500, k_mid4r);
     time_it("middle4 static shape", 500, k_mid4);
     time_it("step with middle4 static", 500, [&]() { k_first(); k_mid4(); k_grad(); });
+    time_it("middle4 static shape, K slabs", 500, [&]() { hipLaunchKernelGGL((middle4_kernel<SS, 0, 0, true, false, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4); });
     time_it("grad_update<fused>", 500, k_grad);
     time_it("grad_update<store G>", 500, k_grad_nf);
     {
@@ -122,11 +132,12 @@ int main(int argc, char **argv) {
         printf("\n");
     }
     {
-        for (int variant = 0; variant < 2; variant++) {
-        if (variant) hipLaunchKernelGGL((middle4_kernel<SS, 0, 0, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
+        for (int variant = 0; variant < 3; variant++) {
+        if (variant == 2) hipLaunchKernelGGL((middle4_kernel<SS, 0, 0, true, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
+        else if (variant) hipLaunchKernelGGL((middle4_kernel<SS, 0, 0, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
         else hipLaunchKernelGGL((middle4_kernel<RuntimeShape<4>, 0, 0, true, true>), dim3((B + 3) / 4), dim3(1024), lds4, s, m4);
         CK(hipStreamSynchronize(s));
-        printf("%s:\n", variant ? "STATIC shape" : "RUNTIME shape");
+        printf("%s:\n", variant == 2 ? "STATIC shape, K slabs" : variant ? "STATIC shape" : "RUNTIME shape");
         std::vector<unsigned long long> hs(2 * 32 * 16);
         CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
         for (int wg : {0, 31, 32, 63}) printf("middle4 stamps wg %d%s: load+stage=%llu fwdL2=%llu fwdL3=%llu output=%llu bwd2=%llu bwd1=%llu total=%llu\n", wg % 32, wg >= 32 ? " (2nd pass)" : "",
