@@ -157,23 +157,47 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     };
     auto frag_tr = [&](const __bf16 *img, int ldt, int c0, int kk) { return tr_frag(img, ldt, c0, kk, lane); };
 
-    auto multiply = [&](int k0) {
-        const int kmax = (p.K - k0 < BK) ? p.K - k0 : BK; // K is a multiple of 16; rows past it were staged as zeros
+    // Fragments of the NEXT 32-wide k block are read while this block's MFMAs issue (as in gemm_f32_kernel): a bf16 block is
+    // only TM*TN MFMAs of 16 cycles, far less than an LDS round trip, and with one workgroup per CU nothing else covers it.
+    auto read_block = [&](int kk, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 32) {
-            if (kk >= kmax) break;
-            bf16x8 a[TM], b[TN];
+        for (int i = 0; i < TM; i++)
+            a[i] = A_KC ? frag_kc(As, wm * (TM * 16) + i * 16, kk) : frag_tr(As, LDTA, wm * (TM * 16) + i * 16, kk);
 #pragma unroll
-            for (int i = 0; i < TM; i++)
-                a[i] = A_KC ? frag_kc(As, wm * (TM * 16) + i * 16, kk) : frag_tr(As, LDTA, wm * (TM * 16) + i * 16, kk);
+        for (int j = 0; j < TN; j++)
+            b[j] = B_KC ? frag_kc(Bs, wn * (TN * 16) + j * 16, kk) : frag_tr(Bs, LDTB, wn * (TN * 16) + j * 16, kk);
+    };
+    auto mfma_block = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
-                b[j] = B_KC ? frag_kc(Bs, wn * (TN * 16) + j * 16, kk) : frag_tr(Bs, LDTB, wn * (TN * 16) + j * 16, kk);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    auto multiply = [&](int k0) {
+        const int kmax = (p.K - k0 < BK) ? p.K - k0 : BK; // K is a multiple of 16; rows past it were staged as zeros
+        if (kmax < BK) { // ragged last tile: plain loop
+            for (int kk = 0; kk < kmax; kk += 32) {
+                bf16x8 a[TM], b[TN];
+                read_block(kk, a, b);
+                mfma_block(a, b);
+            }
+            return;
+        }
+        bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+        read_block(0, a0, b0);
 #pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int kk = 0; kk < BK; kk += 64) {
+            if (kk + 32 < BK) read_block(kk + 32, a1, b1);
+            mfma_block(a0, b0);
+            if (kk + 32 < BK) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0); // the next block's LDS reads first
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                            // then this block's MFMAs
+            if (kk + 32 < BK) {
+                if (kk + 64 < BK) read_block(kk + 64, a0, b0);
+                mfma_block(a1, b1);
+                if (kk + 64 < BK) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            }
         }
     };
     load_tiles(0, ra0, rb0);
