@@ -471,7 +471,7 @@ def test_two_launch_step_chain(gnn, oracle_mod, monkeypatch, dims, B, inner):
     (1) the three-launch path GNN_MLP_CHAIN=0 (same arithmetic up to the summation order of the first layer),
     (2) itself, cut into calls differently and with / without next-batch hints: BITWISE,
     (3) the fp64 oracle."""
-    if os.environ.get("GNN_MLP_PATH"):
+    if os.environ.get("GNN_MLP_PATH") or os.environ.get("GNN_MLP_CHAIN") == "0":
         pytest.skip("path forced by the environment")
     nb, n = 5, 12
     X, Y = make_batch(dims, B * nb, seed=61, sparse=True)
