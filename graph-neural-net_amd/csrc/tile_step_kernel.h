@@ -54,6 +54,10 @@ struct TileStepParams {
     // GNN_DTYPE_BF16 (tile_step_bf16_kernel): the bf16 roundings of the operands, same shapes and leading dimensions
     const __bf16 *Ab[MAX_LAYERS]; const __bf16 *Db[MAX_LAYERS]; __bf16 *Wb[MAX_LAYERS];
     const __bf16 *Anb;
+    // A sampled next batch (next_idx != null): the workgroups of tile column 0 also write the rows they fetched to a
+    // contiguous copy [next_K][ldan] (f32 or bf16 by kernel), which the NEXT step's gradient product then reads in place of
+    // the index-gathered rows -- no dependent index load at the start of that kernel.  Null = no copy.
+    float *stage_out; __bf16 *stage_out_b;
 };
 
 #define GNN_TS_STAMP(i)                                                                                  \
@@ -129,10 +133,14 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     // (fr, fq) -> row fr, inputs 16c + 4fq .. +3 of the tile (c = 0..3).  Straight to registers: A_0' is
     // k-contiguous, no wave shares another's rows, and the product below needs no LDS image of it.
     f32x4 vn[4];
+    // a sampled next batch: this lane's row index of the first chunk is fetched NOW, so that the row loads, requested
+    // ~3 000 cycles from here, do not start with a dependent round trip
+    int next_row0 = wave * 16 + fr;
+    if (fwd && p.next_idx && next_row0 < p.next_rows) next_row0 = p.next_idx[next_row0];
     auto load_next = [&](int b0) {
         const int b = b0 + wave * 16 + fr;
         const bool live = b < p.next_rows;
-        const size_t row = live ? (p.next_idx ? (size_t)p.next_idx[b] : (size_t)b) : 0;
+        const size_t row = live ? (b0 == 0 ? (size_t)next_row0 : p.next_idx ? (size_t)p.next_idx[b] : (size_t)b) : 0;
         const float *src = p.An + row * p.ldan + m0 + 4 * fq;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -244,6 +252,12 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
         for (int j = 0; j < 4; j++) wv[c][j] = wcol[(c * 16 + j) * LDW];
     for (int b0 = 0; b0 < p.next_K; b0 += TS_KC) {
         if (b0) load_next(b0);
+        if (p.stage_out && tn == 0 && b0 + wave * 16 < p.next_K) { // (rows past the batch and columns past M are zeros in vn)
+            float *dst = p.stage_out + (size_t)(b0 + wave * 16 + fr) * p.ldan + m0 + 4 * fq;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (m0 + c * 16 + 4 * fq < L.M) *reinterpret_cast<f32x4 *>(dst + c * 16) = vn[c];
+        }
         if (b0 + wave * 16 < p.next_K) { // wave-uniform
             f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -330,10 +344,12 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
     }
     // next batch: lane (fr, fg) of wave w -> row 16w + fr; per 32-wide k block the inputs 4fg..4fg+3 and 16+4fg..+3
     s16x4 vn[2][2];
+    int next_row0 = wave * 16 + fr; // (as in tile_step_kernel: the index of a sampled next batch's row is fetched ahead)
+    if (fwd && p.next_idx && next_row0 < p.next_rows) next_row0 = p.next_idx[next_row0];
     auto load_next = [&](int b0) {
         const int b = b0 + wave * 16 + fr;
         const bool live = b < p.next_rows;
-        const size_t row = live ? (p.next_idx ? (size_t)p.next_idx[b] : (size_t)b) : 0;
+        const size_t row = live ? (b0 == 0 ? (size_t)next_row0 : p.next_idx ? (size_t)p.next_idx[b] : (size_t)b) : 0;
         const __bf16 *src = p.Anb + row * p.ldan + m0 + 4 * fg;
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
@@ -406,6 +422,14 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
     const bf16x8 w0 = tr_frag(sW, TS_TN, 0, 0, lane), w1 = tr_frag(sW, TS_TN, 0, 32, lane); // A operand: rows n, k = m
     for (int b0 = 0; b0 < p.next_K; b0 += TS_KC) {
         if (b0) load_next(b0);
+        if (p.stage_out_b && tn == 0 && b0 + wave * 16 < p.next_K) {
+            __bf16 *dst = p.stage_out_b + (size_t)(b0 + wave * 16 + fr) * p.ldan + m0 + 4 * fg;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++)
+                    if (m0 + kb * 32 + hh * 16 + 4 * fg < L.M) *reinterpret_cast<s16x4 *>(dst + kb * 32 + hh * 16) = vn[kb][hh];
+        }
         if (b0 + wave * 16 < p.next_K) { // wave-uniform
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, join8(vn[0][0], vn[0][1]), z, 0, 0, 0);
