@@ -1824,7 +1824,9 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    std::mutex mu;
     bool load(std::string *why) {
+        std::lock_guard<std::mutex> lock(mu);
         if (lib) return true;
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);

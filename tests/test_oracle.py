@@ -248,10 +248,10 @@ def test_golden_fixtures_match_oracle(oracle_mod):
 
 
 def test_train_log_row_reproduces_the_references_own_log(tmp_path):
-    """tests/golden/reference_trainLog.csv is the reference's logs/trainLog.csv (5 rows of DATA written by
-    MNISTTrainer.logTest, MT:211-219): the row writer must reproduce each row from its parsed fields."""
+    """tests/golden/reference_train_log_rows.json holds the five rows of the reference's logs/trainLog.csv (DATA written
+    by MNISTTrainer.logTest, MT:211-219): the row writer must reproduce each row from its parsed fields."""
     import gnn_amd
-    rows = open(os.path.join(os.path.dirname(__file__), "golden", "reference_trainLog.csv")).read().splitlines()
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_train_log_rows.json")))["rows"]
     assert len(rows) == 5
     out = tmp_path / "logs" / "trainLog.csv"
     for r in rows:
