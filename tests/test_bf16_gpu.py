@@ -93,3 +93,12 @@ def test_bf16_full_size_properties(gnn):
     h2 = net.calculateWeightGradient(X[B // 2:], Y[B // 2:])
     for l in full:
         assert np.abs(full[l] - (h1[l] + h2[l])).max() <= 1e-5 * np.abs(full[l]).max() + 1e-9
+    # and every element against the bf16-aware fp64 oracle (all tiles of the bf16 GEMM kernels, transpose reads included)
+    Ws = np_oracle.split(net.get_weights(), dims)
+    X32 = X.astype(np.float32).astype(np.float64)
+    gq = np_oracle.gradient_bf16(Ws, X32, Y, LEAKY)
+    off = 0
+    for l in range(len(dims) - 1):
+        n = dims[l] * dims[l + 1]
+        ref_l = gq[off:off + n].reshape(dims[l], dims[l + 1]); off += n
+        assert np.abs(full[l] - ref_l).max() <= 4e-3 * np.abs(ref_l).max() + 1e-7, "layer %d" % l

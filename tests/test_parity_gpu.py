@@ -300,6 +300,23 @@ def test_full_size_configs_properties(gnn, dims, B):
     g8 = net.calculateWeightGradient(X[:8], Y[:8])
     g8f = np.concatenate([g8[l].ravel() for l in sorted(g8)])
     assert np.abs(g8f - gref).max() <= 5e-5 * np.abs(gref).max()
+    # (5) the WHOLE batch against the fp64 matrix-form oracle, every element of every layer's gradient and every
+    # probability: this is what exercises the large-tile GEMM paths (128 x 128 tiles, the 64-wide one-launch gradient)
+    # over ALL their tiles, not a few rows' worth.  With tanh as the inner activation: leaky ReLU's derivative jumps at
+    # 0 (MT:235), and among the ~10^6 hidden pre-activations of these batches a few sit within f32 rounding of 0 and take
+    # the other branch than in fp64 -- one such unit shifts a fifth of a layer's gradient by ~1e-4 of its scale (seen:
+    # 9 % of config 4's first-layer gradient beyond 5e-5), which says nothing about the GEMMs.
+    smooth = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=TANH, max_batch=B)
+    smooth.set_weights(w)
+    _, pr_all = np_oracle.forward(Ws, X, TANH)
+    assert np.abs(smooth.propagate(X) - pr_all).max() <= 5e-4
+    g_all = smooth.calculateWeightGradient(X, Y)
+    gref_all = np_oracle.gradient(Ws, X, Y, TANH)
+    off = 0
+    for l in range(len(dims) - 1):
+        n = dims[l] * dims[l + 1]
+        ref_l = gref_all[off:off + n].reshape(dims[l], dims[l + 1]); off += n
+        assert np.abs(g_all[l] - ref_l).max() <= 5e-5 * np.abs(ref_l).max() + 1e-9, "layer %d" % l
     net.upload_dataset(X, Y)
     other = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
     other.set_weights(w)
