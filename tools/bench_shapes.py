@@ -16,6 +16,6 @@ for dims, B in shapes:
     net.train_range(0, B, 100, 0.0125, 0.9); net.synchronize()
     t0 = time.perf_counter(); net.train_range(0, B, 1000, 0.0125, 0.9); net.synchronize(); dt = time.perf_counter() - t0
     P = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1))
-    print("%-24s B=%-4d specialization=%d  %.2f us/step  %.3g samples/s  %.2f TFLOP/s" % (
-        "-".join(map(str, dims)), B, net.specialization, dt / 1000 * 1e6, 1000 * B / dt,
+    print("%-24s B=%-4d specialization=%d launches=%d  %.2f us/step  %.3g samples/s  %.2f TFLOP/s" % (
+        "-".join(map(str, dims)), B, net.specialization, net.step_launches, dt / 1000 * 1e6, 1000 * B / dt,
         (6 * P - 2 * dims[0] * dims[1]) * B / (dt / 1000) / 1e12), flush=True)
