@@ -7,6 +7,7 @@
 #include "jit.h"
 #include "fused_kernels.h"
 #include "gemm_bf16.h"
+#include "gemm_wavek.h"
 #include "middle4_kernel.h"
 #include "tile_step_kernel.h"
 #include "kernels.h"
@@ -125,6 +126,7 @@ struct gnn_mlp {
     int env_path = 0;          // GNN_MLP_PATH: 0 default, 1 "generic", 2 "nomid4"
     int env_hybrid = -1;       // GNN_MLP_HYBRID: -1 unset, else bit 0 = fwd_first, bit 1 = grad_update
     bool env_tail_off = false; // GNN_MLP_TAIL=0: the three-launch form instead of tail_kernel
+    bool env_wavek_off = false; // GNN_MLP_WAVEK=0: gemm_f32_kernel<32, 32> instead of the wave-K kernel (development)
     bool env_graph = false;    // GNN_MLP_GRAPH=1: train_range replays a captured pass
     bool env_jit_off = false;  // GNN_MLP_JIT=0
     bool env_static_off = false; // GNN_MLP_STATIC=0
@@ -143,6 +145,7 @@ void read_env(gnn_mlp *h) {
     h->env_jit_off = is("GNN_MLP_JIT", "0");
     h->env_static_off = is("GNN_MLP_STATIC", "0");
     h->env_chain_off = is("GNN_MLP_CHAIN", "0");
+    h->env_wavek_off = is("GNN_MLP_WAVEK", "0");
 }
 
 // every launch since the last check was accepted: the runtime's sticky error and the return codes of
@@ -232,9 +235,18 @@ int pick_tile(int M, int N) {
     return 32;
 }
 
+// 32 x 32 tiles, K split over the waves of a workgroup (gemm_wavek.h): for outputs too small for 64-wide tiles to fill
+// the chip.  256 x 1024 x 1024: 9.1 us against 12.2 us for gemm_f32_kernel<32, 32> (profiles/r02/gemm_probe_wavek3.log).
+bool wavek_fits(int M, int N, int K) { return M % 32 == 0 && N % 32 == 0 && K >= 128; }
+template <bool A_KC, bool B_KC, int EPI>
+void launch_gemm_wavek(gnn_mlp *h, int cls, const GemmParams &p) {
+    launch_timed(h, cls, gemm_f32_wavek_kernel<A_KC, B_KC, EPI, 4, 2>, dim3(p.N / 32, p.M / 32), dim3(256), 0, p);
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
     const int tile = pick_tile(p.M, p.N);
+    if (tile == 32 && !h->env_wavek_off && wavek_fits(p.M, p.N, p.K)) { launch_gemm_wavek<A_KC, B_KC, EPI>(h, cls, p); return; }
     // A square grid of 256..511 tiles is ONE 4-wave workgroup per CU: nothing covers its barriers and LDS latencies.
     // Halving the tile along n puts two workgroups on every CU.  (Eight waves on the 64 x 64 tile instead -- WM = 4, two
     // waves per SIMD from one workgroup and a third less operand traffic -- measured 414 vs 420 us/step on config 4 and
@@ -827,6 +839,8 @@ HybridChoice hybrid_choice(const gnn_mlp *h, int B) {
     if (h->env_hybrid >= 0) { c.first = (h->env_hybrid & 1) != 0; c.grad = (h->env_hybrid & 2) != 0; return c; } // tests/development
     const int B_pad = pad_up(B);
     c.first = pick_tile(B_pad, h->ld[1]) == 32;
+    // ... unless the 32 x 32 wave-K GEMM has enough tiles of its own (256 x 784 x 1024: 8.3 us against 13.1 us)
+    if (c.first && !h->env_wavek_off && wavek_fits(B_pad, h->ld[1], h->ld[0]) && (B_pad / 32) * (h->ld[1] / 32) >= 192) c.first = false;
     int64_t big = 0, all = 0; // gradient elements in layers whose GEMM grid would fill the chip on its own
     for (int l = 0; l + 1 < h->L; l++) {
         const int64_t e = (int64_t)h->ld[l] * h->ld[l + 1];

@@ -94,7 +94,9 @@ struct GemmParams {
 
 // WM: wave rows (waves are WM x 2, WM * 128 threads).  WM = 4 puts EIGHT waves on a tile -- two per SIMD from one
 // workgroup, which is what covers barriers and LDS latency when the grid has only one workgroup per CU.
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2>
+// NSTG: k tiles held in registers ahead of the one being multiplied (see the main loop).
+constexpr int gemm_f32_stages(int BM, int BN) { return BM <= 64 ? 2 : 1; }
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2, int NSTG = gemm_f32_stages(BM, BN)>
 __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
     constexpr int NT = WM * 128;
     constexpr int BK = (BM <= 64) ? 64 : 32;    // small tiles do few MFMAs per wave per 32 k: twice the K per barrier pair
@@ -109,10 +111,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
 
     constexpr int NA = BM * BK / 4 / NT, NB = BN * BK / 4 / NT; // float4 per thread per tile
     static_assert(NA >= 1 && NB >= 1 && TM >= 1, "tile too small for this many threads");
-    // TWO register stages for tiles up to 64x64: a single tile of prefetch -- ~1000 cycles of MFMAs
-    // on a 64x64 tile, 256 on a 32x32 one -- does not cover the >=2000 cycles of memory latency;
-    // the loads of tile t+2 are issued before tile t is multiplied
-    float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    float4 ra[NSTG][NA], rb[NSTG][NB];
 
     auto load_tiles = [&](int k0, float4 (&ra)[NA], float4 (&rb)[NB]) {
 #pragma unroll
@@ -243,29 +242,32 @@ __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
         }
     };
-    constexpr bool TWO_STAGES = (BM <= 64); // 128x128 tiles: the second stage would cost a wave of occupancy
-    load_tiles(0, ra0, rb0);
-    if (TWO_STAGES) {
-        if (BK < p.K) load_tiles(BK, ra1, rb1);
-        for (int k0 = 0; k0 < p.K; k0 += 2 * BK) { // two tiles per trip so that the stages keep their names
-            store_tiles(ra0, rb0);
-            __syncthreads();
-            if (k0 + 2 * BK < p.K) load_tiles(k0 + 2 * BK, ra0, rb0);
-            multiply();
-            __syncthreads();
-            if (k0 + BK < p.K) {
-                store_tiles(ra1, rb1);
-                __syncthreads();
-                if (k0 + 3 * BK < p.K) load_tiles(k0 + 3 * BK, ra1, rb1);
-                multiply();
-                __syncthreads();
+    // NSTG register stages: the loads of tile t + NSTG are issued before tile t is multiplied, so NSTG - 1 tiles
+    // (plus the one being staged) are in flight per workgroup.  What a CU must keep in flight is latency x rate: a
+    // 32 x 32 tile with two stages had 32 KB out per CU and ran at 9 B/clk (256 x 1024 x 1024 in 12.6 us);
+    // 128 x 128 tiles take one stage (a second would cost a wave of occupancy).
+    if (NSTG >= 2) {
+#pragma unroll
+        for (int s = 0; s < NSTG; s++)
+            if (s * BK < p.K) load_tiles(s * BK, ra[s], rb[s]);
+        for (int k0 = 0; k0 < p.K; k0 += NSTG * BK) { // NSTG tiles per trip so that the stages keep their names
+#pragma unroll
+            for (int s = 0; s < NSTG; s++) {
+                if (k0 + s * BK < p.K) {
+                    store_tiles(ra[s], rb[s]);
+                    __syncthreads();
+                    if (k0 + (s + NSTG) * BK < p.K) load_tiles(k0 + (s + NSTG) * BK, ra[s], rb[s]);
+                    multiply();
+                    __syncthreads();
+                }
             }
         }
     } else {
+        load_tiles(0, ra[0], rb[0]);
         for (int k0 = 0; k0 < p.K; k0 += BK) {
-            store_tiles(ra0, rb0);
+            store_tiles(ra[0], rb[0]);
             __syncthreads();
-            if (k0 + BK < p.K) load_tiles(k0 + BK, ra0, rb0); // next tile's latency hides under the MFMAs
+            if (k0 + BK < p.K) load_tiles(k0 + BK, ra[0], rb[0]); // next tile's latency hides under the MFMAs
             multiply();
             __syncthreads();
         }

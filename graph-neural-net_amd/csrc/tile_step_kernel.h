@@ -25,7 +25,8 @@
 // calls.
 //
 // All contractions on v_mfma_f32_16x16x4_f32 (exact f32).  8 waves:
-//   gradient: wave -> (m tile of 16 = wave & 3, half of every 128-row K chunk = wave >> 2)
+//   gradient: waves 0..3 -> one m tile of 16 each, product taken transposed (G^T = delta^T . A) so that a lane's
+//             accumulator is four consecutive n of one row of the tile: the 16 B of W / V it updates
 //   forward : wave -> 16 batch rows of every 128-row chunk; K = the tile's 64 input neurons; A_0' rows go
 //             straight to registers in fragment form and the product is taken transposed, so that the
 //             slab is stored 16 B per lane from the accumulators (no LDS image, one barrier in all)
@@ -74,12 +75,9 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     constexpr int LDA = TS_TM + 16;  // gradient A image [k][m]: row stride = 16 (mod 32) floats
     constexpr int LDD = TS_TN;       // delta image [k][n]: 16 floats (lanes 16-31 land on banks 16-31)
     constexpr int LDW = TS_TN + 4;   // weight tile / partial tiles [m][n]
-    constexpr int A_FLOATS = TS_KC * LDA;
-    static_assert(2 * TS_TM * LDW <= A_FLOATS, "the two partial G tiles reuse the A image");
-    __shared__ __attribute__((aligned(16))) float sA[A_FLOATS];         // A chunk; then the two K halves of G
+    __shared__ __attribute__((aligned(16))) float sA[TS_KC * LDA];       // A chunk [128][64]
     __shared__ __attribute__((aligned(16))) float sD[TS_KC * LDD];       // delta chunk [128][16]
-    __shared__ __attribute__((aligned(16))) float sW[TS_TM * LDW];       // the tile's (new) weights
-    float *sC = sA;                                                      // (53 KB in all: two workgroups per CU)
+    __shared__ __attribute__((aligned(16))) float sW[TS_TM * LDW];       // the tile's (new) weights (53 KB in all)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -94,8 +92,9 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     const int m0 = tm * TS_TM, n0 = tn * TS_TN;
     const bool fwd = FWD && li == 0; // block-uniform
 
-    // this thread's 16 B of the weight tile: row er, columns 4*eq .. 4*eq+3 (threads 0..255)
-    const int er = t >> 2, eq = t & 3;
+    // this thread's 16 B of the weight tile (waves 0..3): row er = 16*wave + fr, columns 4*fq .. 4*fq+3 -- the
+    // accumulator layout of the transposed gradient product below, so G never leaves its registers
+    const int er = (t >> 6) * 16 + fr, eq = fq;
     const bool e_ok = t < 256 && (m0 + er < L.M);
     const size_t e_off = (size_t)(m0 + er) * L.ldd + n0 + eq * 4;
 
@@ -152,10 +151,12 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     //  delayed the first barrier by the time its 32 KB take to cross the CU's load path)
     if (fwd && GSRC != 1) load_next(0);
 
-    // ---- gradient tile: G[m][n] = sum_k A[k][m] D[k][n] ------------------------------------------
+    // ---- gradient tile, transposed: G^T[n][m] = sum_k D[k][n] A[k][m] -----------------------------
+    // Waves 0..3 take one 16-wide m tile each over the whole K chunk; lane (fr, fq) ends with G[m = 16 wave + fr]
+    // [n = 4 fq .. 4 fq + 3]: the 16 B of W and V it loaded at the top.  No partial tiles, no second barrier.
+    // (Waves 4..7 sit on the same four SIMDs: splitting K over them bought no MFMA time and cost an LDS round trip.)
     float4 g = g_in;
     if (GSRC == 1) {
-        const int mt = wave & 3, kh = wave >> 2;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         for (int k0 = 0; k0 < p.K; k0 += TS_KC) {
             const int kc = (p.K - k0 < TS_KC) ? p.K - k0 : TS_KC; // a multiple of 16
@@ -187,34 +188,27 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
                 GNN_TS_STAMP(1);
                 if (fwd) load_next(0); // lands under the gradient MFMAs and the update
             }
-            const float *ap = &sA[fq * LDA + mt * 16 + fr];
-            const float *dp = &sD[fq * LDD + fr];
-            const int kbeg = kh * (kc >> 1), kend = kbeg + (kc >> 1); // kc/2 is a multiple of 8
-            int kk = kbeg;
-            for (; kk + 32 <= kend; kk += 32) { // 8 MFMAs per trip, the trip's 16 LDS reads issued first
-                float a[8], d[8];
+            if (wave < 4) {
+                const float *ap = &sA[fq * LDA + wave * 16 + fr];
+                const float *dp = &sD[fq * LDD + fr];
+                int kk = 0;
+                for (; kk + 32 <= kc; kk += 32) { // 8 MFMAs per trip, the trip's 16 LDS reads issued first
+                    float a[8], d[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) { a[j] = ap[(kk + 4 * j) * LDA]; d[j] = dp[(kk + 4 * j) * LDD]; }
+                    for (int j = 0; j < 8; j++) { a[j] = ap[(kk + 4 * j) * LDA]; d[j] = dp[(kk + 4 * j) * LDD]; }
 #pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], d[j], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1], d[j + 1], acc1, 0, 0, 0);
+                    for (int j = 0; j < 8; j += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j], a[j], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j + 1], a[j + 1], acc1, 0, 0, 0);
+                    }
                 }
+                for (; kk < kc; kk += 4)
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[kk * LDD], ap[kk * LDA], acc0, 0, 0, 0);
             }
-            for (; kk < kend; kk += 4)
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * LDA], dp[kk * LDD], acc0, 0, 0, 0);
         }
-        const f32x4 acc = acc0 + acc1;
+        const f32x4 acc = acc0 + acc1; // rows n = 4 fq + r, column m = 16 wave + fr
         GNN_TS_STAMP(2);
-        __syncthreads(); // every wave has finished reading the A image
-#pragma unroll
-        for (int r = 0; r < 4; r++) sC[(kh * TS_TM + mt * 16 + fq * 4 + r) * LDW + fr] = acc[r];
-        __syncthreads();
-        if (t < 256) {
-            const float4 g0 = *reinterpret_cast<const float4 *>(&sC[er * LDW + eq * 4]);
-            const float4 g1 = *reinterpret_cast<const float4 *>(&sC[(TS_TM + er) * LDW + eq * 4]);
-            g = make_float4(g0.x + g1.x, g0.y + g1.y, g0.z + g1.z, g0.w + g1.w);
-        }
+        g = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 
     // ---- store G, or the momentum update (SCE:333-339) -------------------------------------------
@@ -289,10 +283,8 @@ template <int GSRC, int GDST, bool FWD>
 __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepParams p) {
     constexpr int LDA = TS_TM + 16;  // [k][m] bf16 image: 160-B rows (32*odd)
     constexpr int LDD = TS_TN;       // [k][n] bf16 image: 32-B rows
-    constexpr int LDW = TS_TN + 4;   // f32 partial tiles [m][n]
     __shared__ __attribute__((aligned(16))) __bf16 sA[TS_KC * LDA];
     __shared__ __attribute__((aligned(16))) __bf16 sD[TS_KC * LDD];
-    __shared__ __attribute__((aligned(16))) float sC[2 * TS_TM * LDW];
     __shared__ __attribute__((aligned(16))) __bf16 sW[TS_TM * TS_TN]; // the tile's (new) weights [m][n], 32-B rows
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -309,7 +301,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
     const bool fwd = FWD && li == 0;
     const __bf16 *Ab = p.Ab[li], *Db = p.Db[li];
 
-    const int er = t >> 2, eq = t & 3;
+    const int er = (t >> 6) * 16 + fr, eq = fg; // (as in tile_step_kernel: the accumulator layout of the transposed product)
     const bool e_ok = t < 256 && (m0 + er < L.M);
     const size_t e_off = (size_t)(m0 + er) * L.ldd + n0 + eq * 4;
 
@@ -364,8 +356,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
     // ---- gradient tile ------------------------------------------------------------------------------
     float4 g = g_in;
     if (GSRC == 1) {
-        const int mt = wave & 3, kh = wave >> 2;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         for (int k0 = 0; k0 < p.K; k0 += TS_KC) {
             const int kc = (p.K - k0 < TS_KC) ? p.K - k0 : TS_KC;
             if (k0) { __syncthreads(); load_grad(k0, kc); }
@@ -376,22 +367,17 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
             }
             if (t < 256) *reinterpret_cast<bf16x8 *>(&sD[(t >> 1) * LDD + (t & 1) * 8]) = vd;
             __syncthreads();
-            // this wave's half of the chunk's 32-wide k blocks (rows past kc were staged as zeros)
-            for (int kk = kh * 64; kk < kh * 64 + 64; kk += 32) {
-                if (kk >= kc) break;
-                const bf16x8 a = tr_frag(sA, LDA, mt * 16, kk, lane);
-                const bf16x8 b = tr_frag(sD, LDD, 0, kk, lane);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+            // waves 0..3: G^T[n][m] over the chunk's 32-wide k blocks (rows past kc were staged as zeros)
+            if (wave < 4) {
+                for (int kk = 0; kk < kc; kk += 64) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sD, LDD, 0, kk, lane), tr_frag(sA, LDA, wave * 16, kk, lane), acc0, 0, 0, 0);
+                    if (kk + 32 < kc)
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sD, LDD, 0, kk + 32, lane), tr_frag(sA, LDA, wave * 16, kk + 32, lane), acc1, 0, 0, 0);
+                }
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; r++) sC[(kh * TS_TM + mt * 16 + fg * 4 + r) * LDW + fr] = acc[r];
-        __syncthreads();
-        if (t < 256) {
-            const float4 g0 = *reinterpret_cast<const float4 *>(&sC[er * LDW + eq * 4]);
-            const float4 g1 = *reinterpret_cast<const float4 *>(&sC[(TS_TM + er) * LDW + eq * 4]);
-            g = make_float4(g0.x + g1.x, g0.y + g1.y, g0.z + g1.z, g0.w + g1.w);
-        }
+        const f32x4 acc = acc0 + acc1; // rows n = 4 fg + r, column m = 16 wave + fr
+        g = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 
     float4 w_new = w_old;

@@ -290,12 +290,6 @@ def test_full_size_configs_properties(gnn, dims, B):
     Ws = np_oracle.split(w, dims)
     _, pr = np_oracle.forward(Ws, X[:4], 0)
     assert np.abs(p[:4] - pr).max() <= 5e-4
-    full = net.calculateWeightGradient(X, Y)
-    h1 = net.calculateWeightGradient(X[:B // 2], Y[:B // 2])
-    h2 = net.calculateWeightGradient(X[B // 2:], Y[B // 2:])
-    for l in full:
-        scale = np.abs(full[l]).max()
-        assert np.abs(full[l] - (h1[l] + h2[l])).max() <= 1e-5 * scale + 1e-9
     gref = np_oracle.gradient(Ws, X[:8], Y[:8], 0)
     g8 = net.calculateWeightGradient(X[:8], Y[:8])
     g8f = np.concatenate([g8[l].ravel() for l in sorted(g8)])
@@ -308,6 +302,14 @@ def test_full_size_configs_properties(gnn, dims, B):
     # 9 % of config 4's first-layer gradient beyond 5e-5), which says nothing about the GEMMs.
     smooth = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=TANH, max_batch=B)
     smooth.set_weights(w)
+    # (1) linearity, also on tanh: a half batch takes other GEMM kernels than the whole one (fewer rows -> smaller tiles, K
+    # split over the waves), i.e. another summation order, and the same few near-zero pre-activations would flip
+    full = smooth.calculateWeightGradient(X, Y)
+    h1 = smooth.calculateWeightGradient(X[:B // 2], Y[:B // 2])
+    h2 = smooth.calculateWeightGradient(X[B // 2:], Y[B // 2:])
+    for l in full:
+        scale = np.abs(full[l]).max()
+        assert np.abs(full[l] - (h1[l] + h2[l])).max() <= 1e-5 * scale + 1e-9
     _, pr_all = np_oracle.forward(Ws, X, TANH)
     assert np.abs(smooth.propagate(X) - pr_all).max() <= 5e-4
     g_all = smooth.calculateWeightGradient(X, Y)
@@ -422,6 +424,51 @@ def test_hybrid_choices_agree_with_oracle(gnn, oracle_mod, monkeypatch, mask):
         ref.gradient_step(X, Y, 0.0125, 0.9)
     assert np.abs(net.get_weights() - ref.get_weights()).max() <= 3 * W_ATOL
     assert np.abs(net.get_momentum() - ref.get_momentum()).max() <= 3 * W_ATOL
+
+
+@pytest.mark.parametrize("wavek", ["0", None])
+@pytest.mark.parametrize("dims,B", [([304, 512, 288, 10], 30), ([784, 1024, 1024, 1024, 10], 64)])
+def test_wave_k_gemm_agrees_with_oracle(gnn, oracle_mod, monkeypatch, wavek, dims, B):
+    """Outputs of few 32 x 32 tiles take gemm_f32_wavek_kernel (K split over the waves of a workgroup, gemm_wavek.h);
+    GNN_MLP_WAVEK=0 keeps gemm_f32_kernel.  GNN_MLP_HYBRID=0 puts every layer on the per-layer GEMMs.  The first shape
+    has K = 304 (a half chunk at the end), K = 288 (nine chunks on four waves: one wave has none) and 30 live rows of
+    32, against the serial oracle; the second is BASELINE configs[4]'s net at 64 rows against the fp64 matrix form
+    (tanh: see test_full_size_configs_properties on leaky ReLU's derivative at this many units)."""
+    import os
+    from tests import np_oracle
+    if os.environ.get("GNN_MLP_PATH"):
+        pytest.skip("path forced by the environment")
+    monkeypatch.setenv("GNN_MLP_HYBRID", "0")
+    if wavek is None: monkeypatch.delenv("GNN_MLP_WAVEK", raising=False)
+    else: monkeypatch.setenv("GNN_MLP_WAVEK", wavek)
+    X, Y = make_batch(dims, B, seed=123, sparse=True)
+    small = len(dims) == 4
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=LEAKY if small else TANH, max_batch=B)
+    w = net.get_weights() * (0.3 if small else 0.05)
+    net.set_weights(w)
+    w = net.get_weights()
+    if small:
+        ref = oracle_mod.OracleNet(dims)
+        ref.set_alloc_per_sample(0)
+        ref.set_weights(w)
+        pr = ref.propagate(X)
+        gr = sum(ref.calculate_weight_gradient(X[b], Y[b]) for b in range(B))
+    else:
+        Ws = np_oracle.split(w, dims)
+        _, pr = np_oracle.forward(Ws, X, TANH)
+        gr = np_oracle.gradient(Ws, X, Y, TANH)
+    assert np.abs(net.propagate(X) - pr).max() <= P_ATOL
+    g = net.calculateWeightGradient(X, Y)
+    off = 0
+    for l in range(len(dims) - 1):
+        n = dims[l] * dims[l + 1]
+        grl = gr[off:off + n].reshape(dims[l], dims[l + 1]); off += n
+        assert np.abs(g[l] - grl).max() <= 3e-5 * np.abs(grl).max() + 1e-9, "layer %d" % l
+    if small:
+        for s in range(3):
+            net.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+            ref.gradient_step(X, Y, 0.0125, 0.9)
+        assert np.abs(net.get_weights() - ref.get_weights()).max() <= 3 * W_ATOL
 
 
 @pytest.mark.parametrize("tail", ["0", None])

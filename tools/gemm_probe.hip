@@ -1,0 +1,183 @@
+// gemm_probe.hip -- development harness (not shipped): times gemm_f32_kernel instantiations (tile, waves, register
+// stages) on the GEMM shapes of BASELINE configs[3] (4096-2048-2048-1024, 512 rows) and configs[4]
+// (784-1024-1024-1024-10, 256 rows).  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip -o tools/gemm_probe
+#include "../graph-neural-net_amd/csrc/gemm_wavek.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <cmath>
+using namespace gnn;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+static float *dA, *dB, *dC, *dAux, *dW, *dV;
+
+template <int BM, int BN, bool AK, bool BKC, int EPI, int WM, int NSTG>
+void run(const char *what, int M, int N, int K) {
+    GemmParams p{};
+    p.A = dA; p.lda = AK ? K : M;
+    p.B = dB; p.ldb = BKC ? K : N;
+    p.C = dC; p.ldc = N;
+    p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
+    p.aux = dAux; p.ldaux = N; p.W = dW; p.V = dV; p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(WM * 128);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG>), grid, block, 0, 0, p);
+    CK(hipDeviceSynchronize());
+    const int iters = 30;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG>), grid, block, 0, 0, p);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    printf("%-34s %4dx%4dx%4d  tile %3dx%-3d waves %d stages %d  %8.2f us  %6.1f TFLOP/s (%4.1f %%)  %d tiles\n", what, M, N, K, BM, BN, WM * 2, NSTG, us, tf,
+           100.0 * tf / 157.3, (int)(grid.x * grid.y));
+    fflush(stdout);
+}
+
+template <bool AK, bool BKC, int EPI, int NW, int DEPTH>
+void runk(const char *what, int M, int N, int K) {
+    GemmParams p{};
+    p.A = dA; p.lda = AK ? K : M;
+    p.B = dB; p.ldb = BKC ? K : N;
+    p.C = dC; p.ldc = N;
+    p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
+    p.aux = dAux; p.ldaux = N; p.W = dW; p.V = dV; p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
+    dim3 grid(N / 32, M / 32), block(NW * 64);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_f32_wavek_kernel<AK, BKC, EPI, NW, DEPTH>), grid, block, 0, 0, p);
+    CK(hipDeviceSynchronize());
+    const int iters = 30;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_f32_wavek_kernel<AK, BKC, EPI, NW, DEPTH>), grid, block, 0, 0, p);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    printf("%-34s %4dx%4dx%4d  wave-K  32x32  waves %d depth %d   %8.2f us  %6.1f TFLOP/s (%4.1f %%)  %d tiles\n", what, M, N, K, NW, DEPTH, us, tf,
+           100.0 * tf / 157.3, (int)(grid.x * grid.y));
+    fflush(stdout);
+}
+
+// compares the wave-K kernel with gemm_f32_kernel on one shape (max abs difference of C, number of elements off by > 1e-5)
+template <bool AK, bool BKC, int EPI, int NW, int DEPTH>
+void check(int M, int N, int K) {
+    GemmParams p{};
+    p.A = dA; p.lda = AK ? K : M;
+    p.B = dB; p.ldb = BKC ? K : N;
+    p.C = dC; p.ldc = N;
+    p.aux = dW; p.ldaux = N;
+    p.M = M; p.N = N; p.K = K; p.m_true = M - 3; p.n_true = N - 5; p.act = 0;
+    hipLaunchKernelGGL((gemm_f32_kernel<32, 32, AK, BKC, EPI, 2>), dim3(N / 32, M / 32), dim3(256), 0, 0, p);
+    p.C = dAux;
+    hipLaunchKernelGGL((gemm_f32_wavek_kernel<AK, BKC, EPI, NW, DEPTH>), dim3(N / 32, M / 32), dim3(NW * 64), 0, 0, p);
+    std::vector<float> a((size_t)M * N), b((size_t)M * N);
+    CK(hipMemcpy(a.data(), dC, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), dAux, b.size() * 4, hipMemcpyDeviceToHost));
+    double md = 0, mx = 0; size_t bad = 0, first = 0;
+    for (size_t i = 0; i < a.size(); i++) {
+        const double d = fabsf(a[i] - b[i]);
+        if (d > 1e-5 && !bad++) first = i;
+        md = std::max(md, d); mx = std::max(mx, (double)fabsf(a[i]));
+    }
+    printf("check A_KC=%d B_KC=%d epi %d %dx%dx%d waves %d depth %d: max |diff| %.3g (max |C| %.3g), %zu elements off", AK, BKC, EPI, M, N, K, NW, DEPTH, md, mx, bad);
+    if (bad) printf(" (first at row %zu col %zu)", first / N, first % N);
+    printf("\n");
+}
+
+int main(int argc, char **argv) {
+    const size_t n = (size_t)4096 * 2048 + 4096;
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; i++) h[i] = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
+    float **bufs[] = {&dA, &dB, &dC, &dAux, &dW, &dV};
+    for (auto b : bufs) { CK(hipMalloc(b, n * 4)); CK(hipMemcpy(*b, h.data(), n * 4, hipMemcpyHostToDevice)); }
+    const int which = argc > 1 ? atoi(argv[1]) : 0;
+    if (which == 8) {
+        check<true, false, EPI_ACT, 4, 2>(256, 2048, 4096); check<true, false, EPI_ACT, 4, 2>(256, 2048, 2048);
+        check<true, false, EPI_STORE, 4, 2>(256, 1024, 2048); check<true, false, EPI_STORE, 4, 2>(512, 1024, 2048);
+        check<true, true, EPI_DACT, 4, 2>(256, 2048, 1024); check<true, true, EPI_DACT, 4, 2>(256, 2048, 2048);
+        check<true, false, EPI_ACT, 4, 2>(256, 1024, 784); check<true, true, EPI_DACT, 4, 2>(256, 1024, 1024);
+        check<false, false, EPI_STORE, 4, 2>(1024, 1024, 256); check<true, false, EPI_ACT, 4, 2>(64, 2048, 4096);
+        return 0;
+    }
+    if (which == 9) {
+        check<true, false, EPI_ACT, 4, 4>(256, 1024, 1024); check<true, false, EPI_ACT, 8, 4>(256, 1024, 784); check<true, true, EPI_ACT, 4, 4>(256, 1024, 1024);
+        check<true, true, EPI_ACT, 8, 2>(256, 1024, 784); check<false, false, EPI_ACT, 4, 4>(1024, 1024, 256); check<false, false, EPI_ACT, 8, 4>(800, 1024, 272);
+        printf("---- wave-K kernel\n");
+        runk<true, false, EPI_ACT, 4, 2>("forward", 256, 1024, 1024);
+        runk<true, false, EPI_ACT, 4, 4>("forward", 256, 1024, 1024);
+        runk<true, false, EPI_ACT, 4, 6>("forward", 256, 1024, 1024);
+        runk<true, false, EPI_ACT, 8, 2>("forward", 256, 1024, 1024);
+        runk<true, false, EPI_ACT, 8, 4>("forward", 256, 1024, 1024);
+        runk<true, false, EPI_ACT, 4, 3>("forward", 256, 1024, 1024);
+        runk<true, false, EPI_ACT, 4, 2>("forward (first layer)", 256, 1024, 784);
+        runk<true, false, EPI_ACT, 4, 4>("forward (first layer)", 256, 1024, 784);
+        runk<true, false, EPI_ACT, 8, 4>("forward (first layer)", 256, 1024, 784);
+        runk<true, true, EPI_DACT, 4, 2>("backward data", 256, 1024, 1024);
+        runk<true, true, EPI_DACT, 4, 4>("backward data", 256, 1024, 1024);
+        runk<true, true, EPI_DACT, 8, 2>("backward data", 256, 1024, 1024);
+        runk<true, true, EPI_DACT, 8, 4>("backward data", 256, 1024, 1024);
+        runk<false, false, EPI_SGD, 4, 2>("gradient + update", 1024, 1024, 256);
+        runk<false, false, EPI_SGD, 8, 1>("gradient + update", 1024, 1024, 256);
+        runk<true, false, EPI_STORE, 4, 4>("logits (configs[3])", 512, 1024, 2048);
+        runk<true, false, EPI_STORE, 8, 4>("logits (configs[3])", 512, 1024, 2048);
+        runk<true, true, EPI_DACT, 4, 4>("backward data 2 (configs[3])", 512, 2048, 1024);
+        runk<true, false, EPI_ACT, 4, 4>("forward 2 (configs[3])", 512, 2048, 2048);
+    }
+    if (which == 0 || which == 5) {
+        printf("---- configs[4]: 784-1024-1024-1024-10, 256 rows\n");
+        run<32, 32, true, false, EPI_ACT, 2, 2>("forward", 256, 1024, 1024);
+        run<32, 32, true, false, EPI_ACT, 2, 4>("forward", 256, 1024, 1024);
+        run<32, 32, true, false, EPI_ACT, 2, 6>("forward", 256, 1024, 1024);
+        run<32, 32, true, false, EPI_ACT, 2, 8>("forward", 256, 1024, 1024);
+        run<64, 32, true, false, EPI_ACT, 2, 2>("forward", 256, 1024, 1024);
+        run<64, 32, true, false, EPI_ACT, 2, 4>("forward", 256, 1024, 1024);
+        run<32, 32, true, false, EPI_ACT, 2, 2>("forward (first layer)", 256, 1024, 784);
+        run<32, 32, true, false, EPI_ACT, 2, 6>("forward (first layer)", 256, 1024, 784);
+        run<32, 32, true, false, EPI_ACT, 2, 8>("forward (first layer)", 256, 1024, 784);
+        run<32, 32, true, true, EPI_DACT, 2, 2>("backward data", 256, 1024, 1024);
+        run<32, 32, true, true, EPI_DACT, 2, 4>("backward data", 256, 1024, 1024);
+        run<32, 32, true, true, EPI_DACT, 2, 6>("backward data", 256, 1024, 1024);
+        run<32, 32, true, true, EPI_DACT, 2, 8>("backward data", 256, 1024, 1024);
+        run<64, 32, false, false, EPI_SGD, 2, 2>("gradient + update", 1024, 1024, 256);
+        run<64, 32, false, false, EPI_SGD, 2, 4>("gradient + update", 1024, 1024, 256);
+        run<32, 32, false, false, EPI_SGD, 2, 2>("gradient + update", 1024, 1024, 256);
+        run<32, 32, false, false, EPI_SGD, 2, 4>("gradient + update", 1024, 1024, 256);
+        run<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update", 1024, 1024, 256);
+        run<64, 32, false, false, EPI_SGD, 2, 2>("gradient + update (first layer)", 784, 1024, 256);
+        run<64, 32, false, false, EPI_SGD, 2, 4>("gradient + update (first layer)", 784, 1024, 256);
+        run<32, 32, false, false, EPI_SGD, 2, 4>("gradient + update (first layer)", 784, 1024, 256);
+    }
+    if (which == 0 || which == 4) {
+        printf("---- configs[3]: 4096-2048-2048-1024, 512 rows\n");
+        run<64, 32, true, false, EPI_ACT, 2, 2>("forward 1", 512, 2048, 4096);
+        run<64, 32, true, false, EPI_ACT, 2, 3>("forward 1", 512, 2048, 4096);
+        run<64, 32, true, false, EPI_ACT, 2, 4>("forward 1", 512, 2048, 4096);
+        run<64, 64, true, false, EPI_ACT, 2, 2>("forward 1", 512, 2048, 4096);
+        run<64, 64, true, false, EPI_ACT, 2, 4>("forward 1", 512, 2048, 4096);
+        run<64, 64, true, false, EPI_ACT, 4, 2>("forward 1", 512, 2048, 4096);
+        run<64, 64, true, false, EPI_ACT, 4, 4>("forward 1", 512, 2048, 4096);
+        run<64, 32, true, false, EPI_ACT, 2, 2>("forward 2", 512, 2048, 2048);
+        run<64, 32, true, false, EPI_ACT, 2, 4>("forward 2", 512, 2048, 2048);
+        run<32, 32, true, false, EPI_STORE, 2, 2>("logits", 512, 1024, 2048);
+        run<32, 32, true, false, EPI_STORE, 2, 4>("logits", 512, 1024, 2048);
+        run<32, 32, true, false, EPI_STORE, 2, 8>("logits", 512, 1024, 2048);
+        run<64, 32, true, false, EPI_STORE, 2, 2>("logits", 512, 1024, 2048);
+        run<64, 32, true, false, EPI_STORE, 2, 4>("logits", 512, 1024, 2048);
+        run<64, 32, true, true, EPI_DACT, 2, 2>("backward data 2", 512, 2048, 1024);
+        run<64, 32, true, true, EPI_DACT, 2, 4>("backward data 2", 512, 2048, 1024);
+        run<64, 32, true, true, EPI_DACT, 2, 2>("backward data 1", 512, 2048, 2048);
+        run<64, 32, true, true, EPI_DACT, 2, 4>("backward data 1", 512, 2048, 2048);
+        run<128, 128, false, false, EPI_SGD, 2, 1>("gradient + update 0", 4096, 2048, 512);
+        run<128, 128, false, false, EPI_SGD, 2, 2>("gradient + update 0", 4096, 2048, 512);
+        run<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 0", 4096, 2048, 512);
+        run<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 0", 4096, 2048, 512);
+        run<128, 128, false, false, EPI_SGD, 2, 1>("gradient + update 1", 2048, 2048, 512);
+        run<128, 128, false, false, EPI_SGD, 2, 2>("gradient + update 1", 2048, 2048, 512);
+        run<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 1", 2048, 2048, 512);
+        run<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 1", 2048, 2048, 512);
+        run<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 2", 2048, 1024, 512);
+        run<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 2", 2048, 1024, 512);
+        run<64, 32, false, false, EPI_SGD, 2, 2>("gradient + update 2", 2048, 1024, 512);
+        run<64, 32, false, false, EPI_SGD, 2, 4>("gradient + update 2", 2048, 1024, 512);
+    }
+    return 0;
+}
