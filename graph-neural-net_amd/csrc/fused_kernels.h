@@ -451,6 +451,10 @@ struct TailParams {
     int act;                      // inner activation (for f')
 };
 
+// grid = (row blocks, column splits): every workgroup of a row block forms the logits and the output rule (redundantly:
+// 16 x K x 16 MACs), split 0 stores them, and each split makes its share of delta_{L-2}'s columns -- 16 workgroups for a
+// 256-row batch became 128, and the column tiles' operands are requested together instead of one dependent round trip per
+// tile (784-1024^3-10 at 256 rows: 12.3 -> see profiles/r02).
 __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
     constexpr int NW = 8, MAXC = 8, RLD = 20;
     __shared__ __attribute__((aligned(16))) float red[NW * 16 * RLD];
@@ -544,11 +548,12 @@ __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
         }
         l += __shfl_xor(l, 1);
         l += __shfl_xor(l, 2);
-        if (p.prob) *reinterpret_cast<f32x4 *>(p.prob + (size_t)row * 16 + q * 4) = pr;
-        if (p.delta_out) *reinterpret_cast<f32x4 *>(p.delta_out + (size_t)row * 16 + q * 4) = dd;
+        const bool writer = blockIdx.y == 0;
+        if (p.prob && writer) *reinterpret_cast<f32x4 *>(p.prob + (size_t)row * 16 + q * 4) = pr;
+        if (p.delta_out && writer) *reinterpret_cast<f32x4 *>(p.delta_out + (size_t)row * 16 + q * 4) = dd;
         *reinterpret_cast<f32x4 *>(&dl[m * RLD + q * 4]) = dd;
         if (has_nan) best = 0;
-        if (q == 0) {
+        if (q == 0 && writer) {
             if (p.loss) p.loss[row] = live_row ? l : 0.f;
             if (p.label) p.label[row] = live_row ? best : -1;
         }
@@ -556,20 +561,36 @@ __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
     if (!p.delta_prev) return;
     __syncthreads();
 
-    // ---- delta_{L-2}[16 x K]: one 16-column tile per wave at a time; k = 4*fq + i for the i-th MFMA on both operands ----
+    // ---- delta_{L-2}[16 x K]: this split's 16-column tiles, dealt to the waves; k = 4*fq + i for the i-th MFMA on both
+    // operands.  Up to TB tiles per trip, every operand of the trip requested before the first is used.
+    constexpr int TB = 4;
     const f32x4 da = *reinterpret_cast<const f32x4 *>(&dl[fr * RLD + 4 * fq]); // delta_{L-1}[m = fr][4fq..4fq+3]
-    for (int nt = wave; nt < k16; nt += NW) {
-        const int n = nt * 16 + fr;
-        const f32x4 wb = *reinterpret_cast<const f32x4 *>(p.W + (size_t)n * 16 + 4 * fq); // W[n][4fq..4fq+3]
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    const int nt_begin = (int)((long)blockIdx.y * k16 / gridDim.y), nt_end = (int)((long)(blockIdx.y + 1) * k16 / gridDim.y);
+    for (int base = nt_begin + wave; base < nt_end; base += NW * TB) {
+        f32x4 wb[TB];
+        float av[TB][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(da[i], wb[i], c, 0, 0, 0);
+        for (int i = 0; i < TB; i++) {
+            const int nt = base + i * NW;
+            const int n = (nt < nt_end ? nt : base) * 16 + fr; // (a tile past the end re-reads the first: never used)
+            wb[i] = *reinterpret_cast<const f32x4 *>(p.W + (size_t)n * 16 + 4 * fq); // W[n][4fq..4fq+3]
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = m0 + fq * 4 + r;
-            const bool live = row < p.B && n < p.k_true;
-            const float a = p.A[(size_t)row * p.lda + n];
-            p.delta_prev[(size_t)row * p.ldp + n] = live ? c[r] * act_prime_from_a(p.act, a) : 0.f;
+            for (int r = 0; r < 4; r++) av[i][r] = p.A[(size_t)(m0 + fq * 4 + r) * p.lda + n];
+        }
+#pragma unroll
+        for (int i = 0; i < TB; i++) {
+            const int nt = base + i * NW;
+            if (nt >= nt_end) break; // wave-uniform
+            const int n = nt * 16 + fr;
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; j++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(da[j], wb[i][j], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = m0 + fq * 4 + r;
+                const bool live = row < p.B && n < p.k_true;
+                p.delta_prev[(size_t)row * p.ldp + n] = live ? c[r] * act_prime_from_a(p.act, av[i][r]) : 0.f;
+            }
         }
     }
 }

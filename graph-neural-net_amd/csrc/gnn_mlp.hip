@@ -869,7 +869,11 @@ void launch_tail(gnn_mlp *h, const float *a0, const float *y, int B, bool backwa
     t.K = h->ld[Lm - 1]; t.k_true = h->dims[Lm - 1];
     t.B = B; t.n_true = h->dims[Lm];
     t.act = h->inner_act;
-    launch_timed(h, -1, tail_kernel, dim3(pad_up(B) / 16), dim3(512), 0, t);
+    // column splits of the delta_{L-2} phase: towards ~128 workgroups, at least 8 column tiles (one per wave) per split
+    const int row_blocks = pad_up(B) / 16, k16 = t.K / 16;
+    int splits = 1;
+    if (t.delta_prev) splits = std::max(1, std::min({8, 128 / row_blocks, k16 / 8}));
+    launch_timed(h, -1, tail_kernel, dim3(row_blocks, splits), dim3(512), 0, t);
 }
 
 // bf16 twin of an A_0 row pointer: the staging rows or the resident dataset
