@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One step's dispatches in order, from a rocprofv3 kernel trace (`--kernel-trace --output-format csv`):
-name, grid, duration and the gap to the previous dispatch's end.  Usage: tools/step_trace.py TRACE.csv [N]
-prints the LAST N dispatches (default 16) -- the tail of the timed loop, past warm-up."""
+name, grid, duration and the gap to the previous dispatch's end.  Usage: tools/step_trace.py TRACE.csv [N [SKIP]]
+prints the LAST N dispatches (default 16) -- the tail of the timed loop, past warm-up -- after dropping the last SKIP."""
 import csv
 import re
 import sys
@@ -15,7 +15,10 @@ def short(name):
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if skip:
+        rows = rows[:-skip]
     rows = rows[-n:]
     prev = None
     tot = 0
