@@ -83,6 +83,44 @@ void check(int M, int N, int K) {
     printf("\n");
 }
 
+// One wave that watches the clocks for `ticks` of the 100 MHz real-time counter: shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+__global__ void clock_watch(unsigned long long *out, unsigned long long ticks) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(32); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
+
+// shader clock while gemm_f32_kernel<128, 128> runs back to back on another stream (and with the chip idle)
+static void clock_under_load() {
+    unsigned long long *d, h[2];
+    CK(hipMalloc(&d, 16));
+    hipStream_t sa, sb;
+    CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    hipLaunchKernelGGL(clock_watch, dim3(1), dim3(64), 0, sb, d, 300000ull);
+    CK(hipStreamSynchronize(sb)); CK(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+    printf("idle chip:                         %.0f MHz\n", (double)h[0] / (double)h[1] * 100.0);
+    GemmParams p{};
+    const int M = 4096, N = 2048, K = 512;
+    p.A = dA; p.lda = M; p.B = dB; p.ldb = N; p.C = dC; p.ldc = N; p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
+    for (int rep = 0; rep < 3; rep++) {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, sa));
+        const int iters = 300;
+        for (int i = 0; i < iters; i++)
+            hipLaunchKernelGGL((gemm_f32_kernel<128, 128, false, false, EPI_STORE, 2>), dim3(N / 128, M / 128), dim3(256), 0, sa, p);
+        CK(hipEventRecord(e1, sa));
+        hipLaunchKernelGGL(clock_watch, dim3(1), dim3(64), 0, sb, d, 1000000ull); // 10 ms inside the ~25 ms of GEMMs
+        CK(hipStreamSynchronize(sb)); CK(hipStreamSynchronize(sa));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+        const double mhz = (double)h[0] / (double)h[1] * 100.0, us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+        printf("under f32 GEMM 4096x2048x512 (128x128 tiles, store epilogue, %d launches back to back): %.0f MHz; %.2f us = %.1f TFLOP/s = %.1f %% of 157.3 "
+               "(%.1f %% of the peak at this clock, 256 CUs x 256 FLOP/clk)\n", iters, mhz, us, tf, 100.0 * tf / 157.3, 100.0 * tf / (256.0 * 256.0 * mhz * 1e6 / 1e12));
+    }
+}
+
 int main(int argc, char **argv) {
     const size_t n = (size_t)4096 * 2048 + 4096;
     std::vector<float> h(n);
@@ -90,6 +128,7 @@ int main(int argc, char **argv) {
     float **bufs[] = {&dA, &dB, &dC, &dAux, &dW, &dV};
     for (auto b : bufs) { CK(hipMalloc(b, n * 4)); CK(hipMemcpy(*b, h.data(), n * 4, hipMemcpyHostToDevice)); }
     const int which = argc > 1 ? atoi(argv[1]) : 0;
+    if (which == 6) { clock_under_load(); return 0; }
     if (which == 8) {
         check<true, false, EPI_ACT, 4, 2>(256, 2048, 4096); check<true, false, EPI_ACT, 4, 2>(256, 2048, 2048);
         check<true, false, EPI_STORE, 4, 2>(256, 1024, 2048); check<true, false, EPI_STORE, 4, 2>(512, 1024, 2048);
