@@ -96,6 +96,7 @@ struct GemmParams {
 // workgroup, which is what covers barriers and LDS latency when the grid has only one workgroup per CU.
 // NSTG: k tiles held in registers ahead of the one being multiplied (see the main loop).
 constexpr int gemm_f32_stages(int BM, int BN) { return BM <= 64 ? 2 : 1; }
+template <bool B> struct BoolC { static constexpr bool value = B; };
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2, int NSTG = gemm_f32_stages(BM, BN)>
 __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
     constexpr int NT = WM * 128;
@@ -113,7 +114,33 @@ __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
     static_assert(NA >= 1 && NB >= 1 && TM >= 1, "tile too small for this many threads");
     float4 ra[NSTG][NA], rb[NSTG][NB];
 
-    auto load_tiles = [&](int k0, float4 (&ra)[NA], float4 (&rb)[NB]) {
+    // A tile wholly inside M x N with K a multiple of BK loads through precomputed per-thread offsets with no bounds test (the
+    // guarded form costs ~13 instructions and an exec-mask branch per 16-B load).  Only for the gradient form (both operands
+    // k-major, 16-B runs along the row): 4096 x 2048 x 512 with the update 86.6 -> 84.3 us, 2048 x 2048 x 512 50.7 -> 48.7 us;
+    // with a k-contiguous operand the unguarded loads were SLOWER (512 x 2048 x 4096: 99.7 -> 114-117 us, with or without a
+    // scheduling fence behind them; profiles/r02/gemm_probe_interior*.log) and those forms keep the guarded loads.
+    const bool interior = !A_KC && !B_KC && (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
+    // (32-bit element offsets from the operand's base: base in SGPRs + one VGPR offset per load; operands are < 2^32 B)
+    unsigned oa[NA], ob[NB];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int idx = t + i * NT;
+        oa[i] = A_KC ? (unsigned)(m0 + idx % BM) * (unsigned)p.lda + (idx / BM) * 4 : (unsigned)(idx / (BM / 4)) * (unsigned)p.lda + m0 + (idx % (BM / 4)) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const int idx = t + i * NT;
+        ob[i] = B_KC ? (unsigned)(n0 + idx % BN) * (unsigned)p.ldb + (idx / BN) * 4 : (unsigned)(idx / (BN / 4)) * (unsigned)p.ldb + n0 + (idx % (BN / 4)) * 4;
+    }
+    const unsigned a_kstride = A_KC ? 1u : (unsigned)p.lda, b_kstride = B_KC ? 1u : (unsigned)p.ldb;
+    auto load_tiles = [&](int k0, float4 (&ra)[NA], float4 (&rb)[NB], auto inside) {
+        if constexpr (decltype(inside)::value) {
+#pragma unroll
+            for (int i = 0; i < NA; i++) ra[i] = *reinterpret_cast<const float4 *>(p.A + (oa[i] + (unsigned)k0 * a_kstride));
+#pragma unroll
+            for (int i = 0; i < NB; i++) rb[i] = *reinterpret_cast<const float4 *>(p.B + (ob[i] + (unsigned)k0 * b_kstride));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int idx = t + i * NT;
@@ -246,32 +273,36 @@ __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
     // (plus the one being staged) are in flight per workgroup.  What a CU must keep in flight is latency x rate: a
     // 32 x 32 tile with two stages had 32 KB out per CU and ran at 9 B/clk (256 x 1024 x 1024 in 12.6 us);
     // 128 x 128 tiles take one stage (a second would cost a wave of occupancy).
-    if (NSTG >= 2) {
+    auto main_loop = [&](auto inside) {
+        if constexpr (NSTG >= 2) {
 #pragma unroll
-        for (int s = 0; s < NSTG; s++)
-            if (s * BK < p.K) load_tiles(s * BK, ra[s], rb[s]);
-        for (int k0 = 0; k0 < p.K; k0 += NSTG * BK) { // NSTG tiles per trip so that the stages keep their names
+            for (int s = 0; s < NSTG; s++)
+                if (s * BK < p.K) load_tiles(s * BK, ra[s], rb[s], inside);
+            for (int k0 = 0; k0 < p.K; k0 += NSTG * BK) { // NSTG tiles per trip so that the stages keep their names
 #pragma unroll
-            for (int s = 0; s < NSTG; s++) {
-                if (k0 + s * BK < p.K) {
-                    store_tiles(ra[s], rb[s]);
-                    __syncthreads();
-                    if (k0 + (s + NSTG) * BK < p.K) load_tiles(k0 + (s + NSTG) * BK, ra[s], rb[s]);
-                    multiply();
-                    __syncthreads();
+                for (int s = 0; s < NSTG; s++) {
+                    if (k0 + s * BK < p.K) {
+                        store_tiles(ra[s], rb[s]);
+                        __syncthreads();
+                        if (k0 + (s + NSTG) * BK < p.K) load_tiles(k0 + (s + NSTG) * BK, ra[s], rb[s], inside);
+                        multiply();
+                        __syncthreads();
+                    }
                 }
             }
+        } else {
+            load_tiles(0, ra[0], rb[0], inside);
+            for (int k0 = 0; k0 < p.K; k0 += BK) {
+                store_tiles(ra[0], rb[0]);
+                __syncthreads();
+                if (k0 + BK < p.K) load_tiles(k0 + BK, ra[0], rb[0], inside); // next tile's latency hides under the MFMAs
+                multiply();
+                __syncthreads();
+            }
         }
-    } else {
-        load_tiles(0, ra[0], rb[0]);
-        for (int k0 = 0; k0 < p.K; k0 += BK) {
-            store_tiles(ra[0], rb[0]);
-            __syncthreads();
-            if (k0 + BK < p.K) load_tiles(k0 + BK, ra[0], rb[0]); // next tile's latency hides under the MFMAs
-            multiply();
-            __syncthreads();
-        }
-    }
+    };
+    if (interior) main_loop(BoolC<true>{});
+    else main_loop(BoolC<false>{});
 
     // epilogue: C/D map of the 16x16 MFMA: tile column gamma = lane&15, tile row rho = (lane>>4)*4 + reg;
     // with the interleaving above, row = base + TM*rho + i and columns base + TN*gamma + (0..TN-1)
