@@ -247,11 +247,21 @@ template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
     const int tile = pick_tile(p.M, p.N);
     if (tile == 32 && !h->env_wavek_off && wavek_fits(p.M, p.N, p.K)) { launch_gemm_wavek<A_KC, B_KC, EPI>(h, cls, p); return; }
-    // A square grid of 256..511 tiles is ONE 4-wave workgroup per CU: nothing covers its barriers and LDS latencies.
-    // Halving the tile along n puts two workgroups on every CU.  (Eight waves on the 64 x 64 tile instead -- WM = 4, two
-    // waves per SIMD from one workgroup and a third less operand traffic -- measured 414 vs 420 us/step on config 4 and
-    // is not used: profiles/r02/f32_gemm_experiments.md.)
-    if (tile == 64 && (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64) < 512) { launch_gemm_t<64, 32, A_KC, B_KC, EPI>(h, cls, p); return; }
+    // A square grid of 256..511 tiles is ONE 4-wave workgroup per CU: nothing covers its barriers and LDS latencies.  Measured
+    // per form with one register stage (profiles/r02/gemm_probe_tiles1.log, 512-row products of 4096-2048-2048-1024):
+    //   forward (A k-contiguous, W k-major): 64 x 32 tiles, two workgroups per CU (512 x 2048 x 4096: 88.2 us; 64 x 64 with
+    //     8 waves 91.8, with 4 waves 100.0);
+    //   backward data (both k-contiguous): 64 x 64 tiles with EIGHT waves -- two per SIMD from one workgroup and a third less
+    //     operand traffic (512 x 2048 x 2048: 49.3 against 52.1 us; x 1024: 26.3 against 28.9);
+    //   gradient (both k-major): 128 x 128 tiles only from 512 of them up; 256..511 of them run as 64 x 64 (2048 x 2048 x 512 with
+    //     the update: 45.0 against 47.8 us).
+    const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64), t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (tile == 64 && t64 < 512) {
+        if constexpr (A_KC && B_KC) launch_gemm_t<64, 64, A_KC, B_KC, EPI, 4>(h, cls, p);
+        else launch_gemm_t<64, 32, A_KC, B_KC, EPI>(h, cls, p);
+        return;
+    }
+    if (tile == 128 && t128 < 512 && !A_KC && !B_KC) { launch_gemm_t<64, 64, A_KC, B_KC, EPI>(h, cls, p); return; }
     switch (tile) {
     case 128: launch_gemm_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;
     case 64: launch_gemm_t<64, 64, A_KC, B_KC, EPI>(h, cls, p); break;

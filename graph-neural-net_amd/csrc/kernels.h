@@ -94,13 +94,18 @@ struct GemmParams {
 
 // WM: wave rows (waves are WM x 2, WM * 128 threads).  WM = 4 puts EIGHT waves on a tile -- two per SIMD from one
 // workgroup, which is what covers barriers and LDS latency when the grid has only one workgroup per CU.
-// NSTG: k tiles held in registers ahead of the one being multiplied (see the main loop).
-constexpr int gemm_f32_stages(int BM, int BN) { return BM <= 64 ? 2 : 1; }
+// NSTG: k tiles held in registers ahead of the one being multiplied (see the main loop).  ONE for every tile: with two, the
+// guarded loads of the stages sit in branches and the compiler's wait-count pass puts s_waitcnt vmcnt(0) at the head of the
+// loop -- both stages drained, the same prefetch distance as one stage, for more registers and code: one stage is 2-8 %
+// faster on every product of configs[3] / [4] (profiles/r02/gemm_probe_stages.log).
+constexpr int gemm_f32_stages(int BM, int BN) { return 1; }
 template <bool B> struct BoolC { static constexpr bool value = B; };
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2, int NSTG = gemm_f32_stages(BM, BN)>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2, int NSTG = gemm_f32_stages(BM, BN), int BK_ = 0>
 __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
     constexpr int NT = WM * 128;
-    constexpr int BK = (BM <= 64) ? 64 : 32;    // small tiles do few MFMAs per wave per 32 k: twice the K per barrier pair
+    // k depth of a staged tile: small tiles do few MFMAs per wave per k -- more K per barrier pair, and per prefetch distance
+    // (32 x 32: 128 deep measured 26.5 us against 29.2 us at 64 on 512 x 1024 x 2048)
+    constexpr int BK = BK_ ? BK_ : (BM <= 32) ? 128 : (BM <= 64) ? 64 : 32;
     constexpr int TM = BM / (WM * 16), TN = BN / 32;   // 16x16 MFMA tiles per wave (waves are WM x 2)
     constexpr int LDAS = BM + 16, LDBS = BN + 16; // row stride = 16 (mod 32) floats: lanes 0-15 / 16-31 hit disjoint banks
     __shared__ __attribute__((aligned(16))) float As[BK * LDAS];

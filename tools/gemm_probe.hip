@@ -12,7 +12,7 @@ using namespace gnn;
 
 static float *dA, *dB, *dC, *dAux, *dW, *dV;
 
-template <int BM, int BN, bool AK, bool BKC, int EPI, int WM, int NSTG>
+template <int BM, int BN, bool AK, bool BKC, int EPI, int WM, int NSTG, int BKT = 0>
 void run(const char *what, int M, int N, int K) {
     GemmParams p{};
     p.A = dA; p.lda = AK ? K : M;
@@ -22,15 +22,15 @@ void run(const char *what, int M, int N, int K) {
     p.aux = dAux; p.ldaux = N; p.W = dW; p.V = dV; p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(WM * 128);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG>), grid, block, 0, 0, p);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG, BKT>), grid, block, 0, 0, p);
     CK(hipDeviceSynchronize());
     const int iters = 30;
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG>), grid, block, 0, 0, p);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG, BKT>), grid, block, 0, 0, p);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-    printf("%-34s %4dx%4dx%4d  tile %3dx%-3d waves %d stages %d  %8.2f us  %6.1f TFLOP/s (%4.1f %%)  %d tiles\n", what, M, N, K, BM, BN, WM * 2, NSTG, us, tf,
+    printf("%-34s %4dx%4dx%4d  tile %3dx%-3d waves %d stages %d BK %3d  %8.2f us  %6.1f TFLOP/s (%4.1f %%)  %d tiles\n", what, M, N, K, BM, BN, WM * 2, NSTG, BKT ? BKT : (BM <= 32 ? 128 : BM <= 64 ? 64 : 32), us, tf,
            100.0 * tf / 157.3, (int)(grid.x * grid.y));
     fflush(stdout);
 }
@@ -129,6 +129,71 @@ int main(int argc, char **argv) {
     for (auto b : bufs) { CK(hipMalloc(b, n * 4)); CK(hipMemcpy(*b, h.data(), n * 4, hipMemcpyHostToDevice)); }
     const int which = argc > 1 ? atoi(argv[1]) : 0;
     if (which == 6) { clock_under_load(); return 0; }
+    if (which == 2) {
+        printf("---- one register stage against two, same k-tile depth (each pair twice)\n");
+        for (int rep = 0; rep < 2; rep++) {
+            run<64, 32, true, false, EPI_ACT, 2, 2>("forward 1", 512, 2048, 4096);
+            run<64, 32, true, false, EPI_ACT, 2, 1>("forward 1", 512, 2048, 4096);
+            run<64, 32, true, false, EPI_ACT, 2, 2>("forward 2", 512, 2048, 2048);
+            run<64, 32, true, false, EPI_ACT, 2, 1>("forward 2", 512, 2048, 2048);
+            run<64, 32, true, true, EPI_DACT, 2, 2>("backward data 1", 512, 2048, 2048);
+            run<64, 32, true, true, EPI_DACT, 2, 1>("backward data 1", 512, 2048, 2048);
+            run<64, 32, true, true, EPI_DACT, 2, 2>("backward data 2", 512, 2048, 1024);
+            run<64, 32, true, true, EPI_DACT, 2, 1>("backward data 2", 512, 2048, 1024);
+            run<32, 32, true, false, EPI_STORE, 2, 2>("logits", 512, 1024, 2048);
+            run<32, 32, true, false, EPI_STORE, 2, 1>("logits", 512, 1024, 2048);
+            run<32, 32, true, false, EPI_STORE, 2, 1, 128>("logits", 512, 1024, 2048);
+            run<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 2", 2048, 1024, 512);
+            run<64, 64, false, false, EPI_SGD, 2, 1>("gradient + update 2", 2048, 1024, 512);
+            run<64, 32, false, false, EPI_SGD, 2, 2>("gradient + update (configs[4])", 1024, 1024, 256);
+            run<64, 32, false, false, EPI_SGD, 2, 1>("gradient + update (configs[4])", 1024, 1024, 256);
+        }
+        return 0;
+    }
+    if (which == 1) {
+        printf("---- tile shapes with one register stage (each twice)\n");
+        for (int rep = 0; rep < 2; rep++) {
+            run<64, 32, true, false, EPI_ACT, 2, 1>("forward 1", 512, 2048, 4096);
+            run<64, 64, true, false, EPI_ACT, 2, 1>("forward 1", 512, 2048, 4096);
+            run<64, 64, true, false, EPI_ACT, 4, 1>("forward 1", 512, 2048, 4096);
+            run<128, 64, true, false, EPI_ACT, 4, 1>("forward 1", 512, 2048, 4096);
+            run<64, 32, true, false, EPI_ACT, 2, 1>("forward 2", 512, 2048, 2048);
+            run<64, 64, true, false, EPI_ACT, 4, 1>("forward 2", 512, 2048, 2048);
+            run<64, 32, true, true, EPI_DACT, 2, 1>("backward data 1", 512, 2048, 2048);
+            run<64, 64, true, true, EPI_DACT, 4, 1>("backward data 1", 512, 2048, 2048);
+            run<64, 32, true, true, EPI_DACT, 2, 1>("backward data 2", 512, 2048, 1024);
+            run<64, 64, true, true, EPI_DACT, 4, 1>("backward data 2", 512, 2048, 1024);
+            run<32, 32, true, false, EPI_STORE, 2, 1>("logits", 512, 1024, 2048);
+            run<64, 32, true, false, EPI_STORE, 2, 1>("logits", 512, 1024, 2048);
+            run<128, 128, false, false, EPI_SGD, 2, 1>("gradient + update 0", 4096, 2048, 512);
+            run<128, 128, false, false, EPI_SGD, 2, 1>("gradient + update 1", 2048, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 2, 1>("gradient + update 1", 2048, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 2, 1>("gradient + update 2", 2048, 1024, 512);
+            run<64, 32, false, false, EPI_SGD, 2, 1>("gradient + update 2", 2048, 1024, 512);
+            runk<true, false, EPI_STORE, 4, 2>("logits (wave-K)", 512, 1024, 2048);
+        }
+        return 0;
+    }
+    if (which == 3) {
+        printf("---- k-tile depth\n");
+        run<64, 32, true, false, EPI_ACT, 2, 2>("forward 1", 512, 2048, 4096);
+        run<64, 32, true, false, EPI_ACT, 2, 1, 64>("forward 1", 512, 2048, 4096);
+        run<64, 32, true, false, EPI_ACT, 2, 1, 128>("forward 1", 512, 2048, 4096);
+        run<64, 32, true, false, EPI_ACT, 2, 2, 128>("forward 1", 512, 2048, 4096);
+        run<64, 64, true, false, EPI_ACT, 2, 1, 128>("forward 1", 512, 2048, 4096);
+        run<64, 64, true, false, EPI_ACT, 4, 1, 128>("forward 1", 512, 2048, 4096);
+        run<64, 64, true, false, EPI_ACT, 4, 2, 128>("forward 1", 512, 2048, 4096);
+        run<64, 32, true, false, EPI_ACT, 2, 1, 128>("forward 2", 512, 2048, 2048);
+        run<64, 32, true, true, EPI_DACT, 2, 2>("backward data 1", 512, 2048, 2048);
+        run<64, 32, true, true, EPI_DACT, 2, 1, 128>("backward data 1", 512, 2048, 2048);
+        run<64, 32, true, true, EPI_DACT, 2, 1, 128>("backward data 2", 512, 2048, 1024);
+        run<32, 32, true, false, EPI_STORE, 2, 1, 128>("logits", 512, 1024, 2048);
+        run<32, 32, true, false, EPI_STORE, 2, 1, 256>("logits", 512, 1024, 2048);
+        run<64, 64, false, false, EPI_SGD, 2, 1, 128>("gradient + update 2", 2048, 1024, 512);
+        run<64, 64, false, false, EPI_SGD, 2, 1, 64>("gradient + update 2", 2048, 1024, 512);
+        run<128, 128, false, false, EPI_SGD, 2, 1, 64>("gradient + update 0", 4096, 2048, 512);
+        return 0;
+    }
     if (which == 8) {
         check<true, false, EPI_ACT, 4, 2>(256, 2048, 4096); check<true, false, EPI_ACT, 4, 2>(256, 2048, 2048);
         check<true, false, EPI_STORE, 4, 2>(256, 1024, 2048); check<true, false, EPI_STORE, 4, 2>(512, 1024, 2048);
