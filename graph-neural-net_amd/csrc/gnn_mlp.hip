@@ -248,16 +248,15 @@ void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
     const int tile = pick_tile(p.M, p.N);
     if (tile == 32 && !h->env_wavek_off && wavek_fits(p.M, p.N, p.K)) { launch_gemm_wavek<A_KC, B_KC, EPI>(h, cls, p); return; }
     // A square grid of 256..511 tiles is ONE 4-wave workgroup per CU: nothing covers its barriers and LDS latencies.  Measured
-    // per form with one register stage (profiles/r02/gemm_probe_tiles1.log, 512-row products of 4096-2048-2048-1024):
-    //   forward (A k-contiguous, W k-major): 64 x 32 tiles, two workgroups per CU (512 x 2048 x 4096: 88.2 us; 64 x 64 with
-    //     8 waves 91.8, with 4 waves 100.0);
-    //   backward data (both k-contiguous): 64 x 64 tiles with EIGHT waves -- two per SIMD from one workgroup and a third less
-    //     operand traffic (512 x 2048 x 2048: 49.3 against 52.1 us; x 1024: 26.3 against 28.9);
-    //   gradient (both k-major): 128 x 128 tiles only from 512 of them up; 256..511 of them run as 64 x 64 (2048 x 2048 x 512 with
-    //     the update: 45.0 against 47.8 us).
+    // per form (profiles/r02/gemm_probe_tiles2.log, 512-row products of 4096-2048-2048-1024, one register stage, unguarded loads):
+    //   forward and backward data (a k-contiguous operand): 64 x 64 tiles with EIGHT waves -- two per SIMD from one workgroup and
+    //     a third less operand traffic than 64 x 32 (512 x 2048 x 4096: 81.3 against 88.3 us; backward 512 x 2048 x 1024: 23.8
+    //     against 30.0);
+    //   gradient (both k-major): 64 x 32 below 512 tiles of 64 x 64; 128 x 128 tiles only from 512 of them up, 256..511 of them
+    //     run as 64 x 64 (2048 x 2048 x 512 with the update: 45.4 against 48.1 us).
     const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64), t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (tile == 64 && t64 < 512) {
-        if constexpr (A_KC && B_KC) launch_gemm_t<64, 64, A_KC, B_KC, EPI, 4>(h, cls, p);
+        if constexpr (A_KC) launch_gemm_t<64, 64, A_KC, B_KC, EPI, 4>(h, cls, p);
         else launch_gemm_t<64, 32, A_KC, B_KC, EPI>(h, cls, p);
         return;
     }

@@ -119,12 +119,13 @@ __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
     static_assert(NA >= 1 && NB >= 1 && TM >= 1, "tile too small for this many threads");
     float4 ra[NSTG][NA], rb[NSTG][NB];
 
-    // A tile wholly inside M x N with K a multiple of BK loads through precomputed per-thread offsets with no bounds test (the
-    // guarded form costs ~13 instructions and an exec-mask branch per 16-B load).  Only for the gradient form (both operands
-    // k-major, 16-B runs along the row): 4096 x 2048 x 512 with the update 86.6 -> 84.3 us, 2048 x 2048 x 512 50.7 -> 48.7 us;
-    // with a k-contiguous operand the unguarded loads were SLOWER (512 x 2048 x 4096: 99.7 -> 114-117 us, with or without a
-    // scheduling fence behind them; profiles/r02/gemm_probe_interior*.log) and those forms keep the guarded loads.
-    const bool interior = !A_KC && !B_KC && (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
+    // A tile wholly inside M x N with K a multiple of BK loads through precomputed per-thread offsets with no bounds test: the
+    // guarded form costs ~13 instructions and an exec-mask branch per 16-B load (~80 instructions per k tile of a 64-wide tile).
+    // With the single register stage this is worth 2-4 % on the gradient form and 4-12 % on the 8-wave 64 x 64 tiles of the
+    // forward / backward-data forms (profiles/r02/gemm_probe_tiles2.log against gemm_probe_tiles1.log).  (With TWO stages the
+    // unguarded k-contiguous loads had been slower: the compiler copied part of the second stage for the loop back-edge and
+    // waited for it right behind the loads.)
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
     // (32-bit element offsets from the operand's base: base in SGPRs + one VGPR offset per load; operands are < 2^32 B)
     unsigned oa[NA], ob[NB];
 #pragma unroll
