@@ -76,7 +76,7 @@ constexpr size_t gemm_bf16_lds_bytes() {
     return sizeof(__bf16) * ((A_KC ? BM * LDK : BK * LDTA) + (B_KC ? BN * LDK : BK * LDTB));
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int NSTG = 2>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     constexpr int BK = GemmBf16Depth<BM>::BK;
     constexpr int TM = BM / 32, TN = BN / 32; // 16x16 MFMA tiles per wave (waves are 2 x 2)
@@ -93,9 +93,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     constexpr int NA = BM * BK / 8 / 256, NB = BN * BK / 8 / 256; // 16-B chunks (8 bf16) per thread per tile
     static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
-    bf16x8 ra0[NA], rb0[NB], ra1[NA], rb1[NB]; // two register stages
+    bf16x8 ra0[NA], rb0[NB], ra1[NA], rb1[NB]; // register stages
 
-    auto load_tiles = [&](int k0, bf16x8 (&ra)[NA], bf16x8 (&rb)[NB]) {
+    // interior tiles (wholly inside M x N, K a multiple of BK): unguarded loads through 32-bit element offsets (see gemm_f32_kernel)
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
+    unsigned oa[NA], ob[NB];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int c = t + i * 256;
+        oa[i] = A_KC ? (unsigned)(m0 + c / (BK / 8)) * (unsigned)p.lda + (c % (BK / 8)) * 8 : (unsigned)(c / (BM / 8)) * (unsigned)p.lda + m0 + (c % (BM / 8)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const int c = t + i * 256;
+        ob[i] = B_KC ? (unsigned)(n0 + c / (BK / 8)) * (unsigned)p.ldb + (c % (BK / 8)) * 8 : (unsigned)(c / (BN / 8)) * (unsigned)p.ldb + n0 + (c % (BN / 8)) * 8;
+    }
+    const unsigned a_kstride = A_KC ? 1u : (unsigned)p.lda, b_kstride = B_KC ? 1u : (unsigned)p.ldb;
+    auto load_tiles = [&](int k0, bf16x8 (&ra)[NA], bf16x8 (&rb)[NB], auto inside) {
+        if constexpr (decltype(inside)::value) {
+#pragma unroll
+            for (int i = 0; i < NA; i++) ra[i] = *reinterpret_cast<const bf16x8 *>(p.A + (oa[i] + (unsigned)k0 * a_kstride));
+#pragma unroll
+            for (int i = 0; i < NB; i++) rb[i] = *reinterpret_cast<const bf16x8 *>(p.B + (ob[i] + (unsigned)k0 * b_kstride));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int c = t + i * 256;
@@ -200,22 +221,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
             }
         }
     };
-    load_tiles(0, ra0, rb0);
-    if (BK < p.K) load_tiles(BK, ra1, rb1);
-    for (int k0 = 0; k0 < p.K; k0 += 2 * BK) { // two tiles per trip so that the stages keep their names
-        store_tiles(ra0, rb0);
-        __syncthreads();
-        if (k0 + 2 * BK < p.K) load_tiles(k0 + 2 * BK, ra0, rb0);
-        multiply(k0);
-        __syncthreads();
-        if (k0 + BK < p.K) {
-            store_tiles(ra1, rb1);
-            __syncthreads();
-            if (k0 + 3 * BK < p.K) load_tiles(k0 + 3 * BK, ra1, rb1);
-            multiply(k0 + BK);
-            __syncthreads();
+    auto main_loop = [&](auto inside) {
+        if constexpr (NSTG >= 2) {
+            load_tiles(0, ra0, rb0, inside);
+            if (BK < p.K) load_tiles(BK, ra1, rb1, inside);
+            for (int k0 = 0; k0 < p.K; k0 += 2 * BK) { // two tiles per trip so that the stages keep their names
+                store_tiles(ra0, rb0);
+                __syncthreads();
+                if (k0 + 2 * BK < p.K) load_tiles(k0 + 2 * BK, ra0, rb0, inside);
+                multiply(k0);
+                __syncthreads();
+                if (k0 + BK < p.K) {
+                    store_tiles(ra1, rb1);
+                    __syncthreads();
+                    if (k0 + 3 * BK < p.K) load_tiles(k0 + 3 * BK, ra1, rb1, inside);
+                    multiply(k0 + BK);
+                    __syncthreads();
+                }
+            }
+        } else {
+            load_tiles(0, ra0, rb0, inside);
+            for (int k0 = 0; k0 < p.K; k0 += BK) {
+                store_tiles(ra0, rb0);
+                __syncthreads();
+                if (k0 + BK < p.K) load_tiles(k0 + BK, ra0, rb0, inside);
+                multiply(k0);
+                __syncthreads();
+            }
         }
-    }
+    };
+    if (interior) main_loop(BoolC<true>{});
+    else main_loop(BoolC<false>{});
 
     // ---- epilogue ------------------------------------------------------------------------------------
     // The accumulator of a 16x16 MFMA tile has its column on the lane (lane & 15) and four rows in the registers:

@@ -288,6 +288,10 @@ void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
     // already from 128 tiles up (f32 wants 256): the 512 x 1024 logits of 4096-2048-2048-1024 took 13.5 us on 32 x 32 tiles
     int tile = pick_tile(p.M, p.N);
     if (tile == 32 && (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64) >= 128) tile = 64;
+    // the gradient form with the update is bound by the masters' traffic in its epilogue, and there more, smaller workgroups
+    // keep more of it in flight: 4096 x 2048 x 512 with the update 41.5 us on 128 x 128 tiles (one workgroup per CU at its
+    // register count), 32.4 us on 64 x 64 (profiles/r02/gemm_probe_bf16_interior.log)
+    if (tile == 128 && !A_KC && !B_KC && EPI == EPI_SGD) tile = 64;
     switch (tile) {
     case 128: launch_gemm_bf16_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;
     case 64: launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI>(h, cls, p); break;

@@ -2,6 +2,7 @@
 // stages) on the GEMM shapes of BASELINE configs[3] (4096-2048-2048-1024, 512 rows) and configs[4]
 // (784-1024-1024-1024-10, 256 rows).  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip -o tools/gemm_probe
 #include "../graph-neural-net_amd/csrc/gemm_wavek.h"
+#include "../graph-neural-net_amd/csrc/gemm_bf16.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -83,6 +84,33 @@ void check(int M, int N, int K) {
     printf("\n");
 }
 
+// bf16 GEMM (gemm_bf16.h) on the same buffers reinterpreted (timing only; values are whatever the bits are)
+template <int BM, int BN, bool AK, bool BKC, int EPI, int NSTG = 2>
+void runb(const char *what, int M, int N, int K) {
+    GemmBf16Params p{};
+    p.A = reinterpret_cast<const __bf16 *>(dA); p.lda = AK ? K : M;
+    p.B = reinterpret_cast<const __bf16 *>(dB); p.ldb = BKC ? K : N;
+    p.C = dC; p.ldc = N; p.Cb = reinterpret_cast<__bf16 *>(dAux);
+    p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
+    p.aux = dW; p.ldaux = N; p.W = dW; p.V = dV; p.Wb = reinterpret_cast<__bf16 *>(dAux); p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
+    if (EPI == EPI_SGD) { p.C = nullptr; p.Cb = nullptr; }
+    constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, AK, BKC>();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(256);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG>), grid, block, lds, 0, p);
+    CK(hipDeviceSynchronize());
+    const int iters = 30;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG>), grid, block, lds, 0, p);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    printf("%-34s %4dx%4dx%4d  bf16 tile %3dx%-3d stages %d  %8.2f us  %6.1f TFLOP/s (%4.1f %% of 2500)  %d tiles\n", what, M, N, K, BM, BN, NSTG, us, tf, 100.0 * tf / 2500.0,
+           (int)(grid.x * grid.y));
+    fflush(stdout);
+}
+
 // One wave that watches the clocks for `ticks` of the 100 MHz real-time counter: shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
 __global__ void clock_watch(unsigned long long *out, unsigned long long ticks) {
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
@@ -128,6 +156,30 @@ int main(int argc, char **argv) {
     float **bufs[] = {&dA, &dB, &dC, &dAux, &dW, &dV};
     for (auto b : bufs) { CK(hipMalloc(b, n * 4)); CK(hipMemcpy(*b, h.data(), n * 4, hipMemcpyHostToDevice)); }
     const int which = argc > 1 ? atoi(argv[1]) : 0;
+    if (which == 10) {
+        printf("---- bf16 GEMMs of configs[3] (each twice)\n");
+        for (int rep = 0; rep < 2; rep++) {
+            runb<64, 64, true, false, EPI_ACT, 2>("forward 1", 512, 2048, 4096);
+            runb<64, 64, true, false, EPI_ACT, 1>("forward 1", 512, 2048, 4096);
+            runb<64, 64, true, false, EPI_ACT, 2>("forward 2", 512, 2048, 2048);
+            runb<64, 64, true, false, EPI_ACT, 1>("forward 2", 512, 2048, 2048);
+            runb<64, 64, true, false, EPI_STORE, 2>("logits", 512, 1024, 2048);
+            runb<64, 64, true, false, EPI_STORE, 1>("logits", 512, 1024, 2048);
+            runb<64, 64, true, true, EPI_DACT, 2>("backward data 2", 512, 2048, 1024);
+            runb<64, 64, true, true, EPI_DACT, 1>("backward data 2", 512, 2048, 1024);
+            runb<64, 64, true, true, EPI_DACT, 2>("backward data 1", 512, 2048, 2048);
+            runb<64, 64, true, true, EPI_DACT, 1>("backward data 1", 512, 2048, 2048);
+            runb<128, 128, false, false, EPI_SGD, 2>("gradient + update 0", 4096, 2048, 512);
+            runb<128, 128, false, false, EPI_SGD, 1>("gradient + update 0", 4096, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2>("gradient + update 0", 4096, 2048, 512);
+            runb<128, 128, false, false, EPI_SGD, 2>("gradient + update 1", 2048, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2>("gradient + update 1", 2048, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 1>("gradient + update 1", 2048, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2>("gradient + update 2", 2048, 1024, 512);
+            runb<64, 64, false, false, EPI_SGD, 1>("gradient + update 2", 2048, 1024, 512);
+        }
+        return 0;
+    }
     if (which == 6) { clock_under_load(); return 0; }
     if (which == 2) {
         printf("---- one register stage against two, same k-tile depth (each pair twice)\n");
