@@ -226,6 +226,27 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (which == 11) {
+        printf("---- unguarded loads: one register stage against two (each twice)\n");
+        for (int rep = 0; rep < 2; rep++) {
+            run<64, 64, true, false, EPI_ACT, 4, 1>("forward 1", 512, 2048, 4096);
+            run<64, 64, true, false, EPI_ACT, 4, 2>("forward 1", 512, 2048, 4096);
+            run<64, 64, true, false, EPI_ACT, 4, 1>("forward 2", 512, 2048, 2048);
+            run<64, 64, true, false, EPI_ACT, 4, 2>("forward 2", 512, 2048, 2048);
+            run<64, 64, true, true, EPI_DACT, 4, 1>("backward data 1", 512, 2048, 2048);
+            run<64, 64, true, true, EPI_DACT, 4, 2>("backward data 1", 512, 2048, 2048);
+            run<64, 64, true, true, EPI_DACT, 4, 1>("backward data 2", 512, 2048, 1024);
+            run<64, 64, true, true, EPI_DACT, 4, 2>("backward data 2", 512, 2048, 1024);
+            run<128, 128, false, false, EPI_SGD, 2, 1>("gradient + update 0", 4096, 2048, 512);
+            run<128, 128, false, false, EPI_SGD, 2, 2>("gradient + update 0", 4096, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 2, 1>("gradient + update 1", 2048, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 1", 2048, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 4, 1>("gradient + update 1", 2048, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 2, 1>("gradient + update 2", 2048, 1024, 512);
+            run<64, 64, false, false, EPI_SGD, 4, 1>("gradient + update 2", 2048, 1024, 512);
+        }
+        return 0;
+    }
     if (which == 3) {
         printf("---- k-tile depth\n");
         run<64, 32, true, false, EPI_ACT, 2, 2>("forward 1", 512, 2048, 4096);
