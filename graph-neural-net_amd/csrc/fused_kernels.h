@@ -32,15 +32,20 @@ constexpr int MAX_LAYERS = 8;
 // ------------------------------------------------------------------------------------------
 struct XcdTiling {
     int tiles_m, tiles_n; // real tile counts
-    int xn;               // rectangles along n (xm = 8 / xn)
+    int xn;               // rectangles along n (xm = 8 / xn), a power of two
     int rm, rn;           // rectangle extent in tiles
+    int xs;               // log2(xn)
+    float inv_rn;         // 1 / rn
     __host__ __device__ int blocks() const { return 8 * rm * rn; }
-    // local block id -> tile; false = idle block
+    // local block id -> tile; false = idle block.  Every workgroup runs this before its first load: no integer division
+    // (two of them were ~50 instructions): xn is a power of two, and j / rn through the reciprocal is exact for these sizes
+    // ((j + 0.5) / rn is at least 0.5 / rn away from an integer; j, rn < 2^16).
     __device__ __forceinline__ bool tile_of(int id, int &tm, int &tn) const {
         const int x = id & 7, j = id >> 3;
-        tm = (x / xn) * rm + j / rn;
-        tn = (x % xn) * rn + j % rn;
-        return tm < tiles_m && tn < tiles_n && (j / rn) < rm;
+        const int q = (int)(((float)j + 0.5f) * inv_rn);
+        tm = (x >> xs) * rm + q;
+        tn = (x & (xn - 1)) * rn + (j - q * rn);
+        return tm < tiles_m && tn < tiles_n && q < rm;
     }
 };
 __host__ inline XcdTiling make_xcd_tiling(int tiles_m, int tiles_n) {
@@ -50,7 +55,12 @@ __host__ inline XcdTiling make_xcd_tiling(int tiles_m, int tiles_n) {
         const int xm = 8 / xn;
         const int rm = (tiles_m + xm - 1) / xm, rn = (tiles_n + xn - 1) / xn;
         const long cost = (long)(rm + rn) * 1000 + (long)rm * rn; // panels fetched per XCD, then idle blocks
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = XcdTiling{tiles_m, tiles_n, xn, rm, rn}; }
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            int xs = 0;
+            while ((1 << xs) < xn) xs++;
+            best = XcdTiling{tiles_m, tiles_n, xn, rm, rn, xs, 1.0f / (float)rn};
+        }
     }
     return best;
 }

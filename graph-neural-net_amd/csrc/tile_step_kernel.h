@@ -86,7 +86,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
 #pragma unroll
     for (int i = 1; i < MAX_LAYERS; i++)
         if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].block_begin) li = i;
-    const GradLayer &L = p.layer[li];
+    const GradLayer L = p.layer[li]; // by value: one batch of scalar loads, not one round trip per field as it is first used
     int tm, tn;
     if (!L.tiling.tile_of(blockIdx.x - L.block_begin, tm, tn)) return;
     const int m0 = tm * TS_TM, n0 = tn * TS_TN;
@@ -104,7 +104,17 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     // gradient operands of the first K chunk
     float4 va[4], vd;
     const int kc0 = (p.K < TS_KC) ? p.K : TS_KC;
-    if (GSRC == 1) {
+    // A tile wholly inside its layer, a whole first chunk, rows in place: no bounds tests, no exec-mask branches -- every wave
+    // runs this prologue before the first barrier, and a guarded 16-B load is ~13 instructions (see gemm_f32_kernel)
+    const bool interior = (m0 + TS_TM <= L.M) && (p.K >= TS_KC) && !(li == 0 && p.row_idx);
+    if (GSRC == 1 && interior) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = t + i * TS_THREADS, k = idx >> 4, q = idx & 15;
+            va[i] = *reinterpret_cast<const float4 *>(L.A + ((unsigned)k * (unsigned)L.lda + m0 + q * 4));
+        }
+        vd = *reinterpret_cast<const float4 *>(L.D + ((unsigned)(t >> 2) * (unsigned)L.ldd + n0 + (t & 3) * 4));
+    } else if (GSRC == 1) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int idx = t + i * TS_THREADS, k = idx >> 4, q = idx & 15;
@@ -128,6 +138,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
         if (GDST == 2) v_old = *reinterpret_cast<const float4 *>(L.V + e_off);
         if (GSRC == 2) g_in = *reinterpret_cast<const float4 *>(L.G + e_off);
     }
+    const bool next_plain = interior && fwd && !p.next_idx && p.next_rows >= TS_KC; // the first chunk of the next batch: all rows live, in place
     // the next batch's rows, already in MFMA fragment form: wave -> 16 batch rows of a 128-row chunk, lane
     // (fr, fq) -> row fr, inputs 16c + 4fq .. +3 of the tile (c = 0..3).  Straight to registers: A_0' is
     // k-contiguous, no wave shares another's rows, and the product below needs no LDS image of it.
@@ -138,6 +149,12 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     if (fwd && p.next_idx && next_row0 < p.next_rows) next_row0 = p.next_idx[next_row0];
     auto load_next = [&](int b0) {
         const int b = b0 + wave * 16 + fr;
+        if (b0 == 0 && next_plain) { // (block-uniform)
+            const float *src = p.An + ((unsigned)b * (unsigned)p.ldan + m0 + 4 * fq);
+#pragma unroll
+            for (int c = 0; c < 4; c++) vn[c] = *reinterpret_cast<const f32x4 *>(src + c * 16);
+            return;
+        }
         const bool live = b < p.next_rows;
         const size_t row = live ? (b0 == 0 ? (size_t)next_row0 : p.next_idx ? (size_t)p.next_idx[b] : (size_t)b) : 0;
         const float *src = p.An + row * p.ldan + m0 + 4 * fq;
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
 #pragma unroll
     for (int i = 1; i < MAX_LAYERS; i++)
         if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].block_begin) li = i;
-    const GradLayer &L = p.layer[li];
+    const GradLayer L = p.layer[li]; // by value: one batch of scalar loads, not one round trip per field as it is first used
     int tm, tn;
     if (!L.tiling.tile_of(blockIdx.x - L.block_begin, tm, tn)) return;
     const int m0 = tm * TS_TM, n0 = tn * TS_TN;
