@@ -368,6 +368,8 @@ __global__ __launch_bounds__(512) void grad_update64_kernel(GradParams p) {
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // tiles wholly inside their layer with the batch rows in place load without bounds tests (see gemm_f32_kernel)
+    const bool interior = (m0 + T <= L.M) && (n0 + T <= L.N) && (p.K % KC == 0) && !(li == 0 && p.row_idx);
     for (int k0 = 0; k0 < p.K; k0 += KC) {
         const int kc = (p.K - k0 < KC) ? p.K - k0 : KC; // a multiple of 16
         if (k0) __syncthreads();
@@ -376,7 +378,10 @@ __global__ __launch_bounds__(512) void grad_update64_kernel(GradParams p) {
         for (int i = 0; i < KC * 16 / 512; i++) {
             const int idx = t + i * 512, k = idx >> 4, q = idx & 15;
             float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vd = va;
-            if (k < kc) {
+            if (interior) { // block-uniform
+                va = *reinterpret_cast<const float4 *>(L.A + ((unsigned)(k0 + k) * (unsigned)L.lda + m0 + q * 4));
+                vd = *reinterpret_cast<const float4 *>(L.D + ((unsigned)(k0 + k) * (unsigned)L.ldd + n0 + q * 4));
+            } else if (k < kc) {
                 size_t a_row = (size_t)(k0 + k);
                 bool a_live = true;
                 if (li == 0 && p.row_idx) {
