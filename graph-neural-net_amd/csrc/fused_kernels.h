@@ -369,7 +369,8 @@ __global__ __launch_bounds__(512) void grad_update64_kernel(GradParams p) {
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // tiles wholly inside their layer with the batch rows in place load without bounds tests (see gemm_f32_kernel)
-    const bool interior = (m0 + T <= L.M) && (n0 + T <= L.N) && (p.K % KC == 0) && !(li == 0 && p.row_idx);
+    const bool interior = (m0 + T <= L.M) && (n0 + T <= L.N) && (p.K % KC == 0) && !(li == 0 && p.row_idx) &&
+                          (unsigned long long)p.K * (unsigned)(L.lda > L.ldd ? L.lda : L.ldd) < 0xffffffffull; // 32-bit offsets
     for (int k0 = 0; k0 < p.K; k0 += KC) {
         const int kc = (p.K - k0 < KC) ? p.K - k0 : KC; // a multiple of 16
         if (k0) __syncthreads();

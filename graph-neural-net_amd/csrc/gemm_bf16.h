@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     bf16x8 ra0[NA], rb0[NB], ra1[NA], rb1[NB]; // register stages
 
     // interior tiles (wholly inside M x N, K a multiple of BK): unguarded loads through 32-bit element offsets (see gemm_f32_kernel)
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
+    const bool fits32 = (unsigned long long)(A_KC ? p.M : p.K) * (unsigned)p.lda < 0xffffffffull &&
+                        (unsigned long long)(B_KC ? p.N : p.K) * (unsigned)p.ldb < 0xffffffffull;
+    const bool interior = fits32 && (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
     unsigned oa[NA], ob[NB];
 #pragma unroll
     for (int i = 0; i < NA; i++) {

@@ -125,7 +125,9 @@ __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
     // forward / backward-data forms (profiles/r02/gemm_probe_tiles2.log against gemm_probe_tiles1.log).  (With TWO stages the
     // unguarded k-contiguous loads had been slower: the compiler copied part of the second stage for the loop back-edge and
     // waited for it right behind the loads.)
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
+    const bool fits32 = (unsigned long long)(A_KC ? p.M : p.K) * (unsigned)p.lda < 0xffffffffull &&
+                        (unsigned long long)(B_KC ? p.N : p.K) * (unsigned)p.ldb < 0xffffffffull; // 32-bit element offsets below
+    const bool interior = fits32 && (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
     // (32-bit element offsets from the operand's base: base in SGPRs + one VGPR offset per load; operands are < 2^32 B)
     unsigned oa[NA], ob[NB];
 #pragma unroll

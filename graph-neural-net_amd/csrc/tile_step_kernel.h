@@ -106,7 +106,8 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     const int kc0 = (p.K < TS_KC) ? p.K : TS_KC;
     // A tile wholly inside its layer, a whole first chunk, rows in place: no bounds tests, no exec-mask branches -- every wave
     // runs this prologue before the first barrier, and a guarded 16-B load is ~13 instructions (see gemm_f32_kernel)
-    const bool interior = (m0 + TS_TM <= L.M) && (p.K >= TS_KC) && !(li == 0 && p.row_idx);
+    const bool interior = (m0 + TS_TM <= L.M) && (p.K >= TS_KC) && !(li == 0 && p.row_idx) &&
+                          (unsigned long long)TS_KC * (unsigned)(L.lda > L.ldd ? L.lda : L.ldd) < 0xffffffffull; // 32-bit offsets
     if (GSRC == 1 && interior) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
         if (GDST == 2) v_old = *reinterpret_cast<const float4 *>(L.V + e_off);
         if (GSRC == 2) g_in = *reinterpret_cast<const float4 *>(L.G + e_off);
     }
-    const bool next_plain = interior && fwd && !p.next_idx && p.next_rows >= TS_KC; // the first chunk of the next batch: all rows live, in place
+    const bool next_plain = interior && fwd && !p.next_idx && p.next_rows >= TS_KC && (unsigned long long)TS_KC * (unsigned)p.ldan < 0xffffffffull; // the first chunk of the next batch: all rows live, in place
     // the next batch's rows, already in MFMA fragment form: wave -> 16 batch rows of a 128-row chunk, lane
     // (fr, fq) -> row fr, inputs 16c + 4fq .. +3 of the tile (c = 0..3).  Straight to registers: A_0' is
     // k-contiguous, no wave shares another's rows, and the product below needs no LDS image of it.
