@@ -427,18 +427,20 @@ def test_hybrid_choices_agree_with_oracle(gnn, oracle_mod, monkeypatch, mask):
 
 
 @pytest.mark.parametrize("wavek", ["0", None])
-@pytest.mark.parametrize("dims,B", [([304, 512, 288, 10], 30), ([784, 1024, 1024, 1024, 10], 64)])
+@pytest.mark.parametrize("dims,B", [([304, 512, 288, 10], 30), ([160, 128, 96, 10], 60), ([784, 1024, 1024, 1024, 10], 64)])
 def test_wave_k_gemm_agrees_with_oracle(gnn, oracle_mod, monkeypatch, wavek, dims, B):
     """Outputs of few 32 x 32 tiles take gemm_f32_wavek_kernel (K split over the waves of a workgroup, gemm_wavek.h);
     GNN_MLP_WAVEK=0 keeps gemm_f32_kernel.  GNN_MLP_HYBRID=0 puts every layer on the per-layer GEMMs.  The first shape
     has K = 304 (a half chunk at the end), K = 288 (nine chunks on four waves: one wave has none) and 30 live rows of
-    32, against the serial oracle; the second is BASELINE configs[4]'s net at 64 rows against the fp64 matrix form
-    (tanh: see test_full_size_configs_properties on leaky ReLU's derivative at this many units)."""
+    32, against the serial oracle; the second (forced onto the per-layer path: its weights would fit the row-block
+    kernel) has K = 160 and 128 -- five and four chunks on four waves -- and 60 live rows of 64; the third is BASELINE configs[4]'s net at 64 rows against the fp64 matrix form (tanh: see
+    test_full_size_configs_properties on leaky ReLU's derivative at this many units)."""
     import os
     from tests import np_oracle
     if os.environ.get("GNN_MLP_PATH"):
         pytest.skip("path forced by the environment")
     monkeypatch.setenv("GNN_MLP_HYBRID", "0")
+    if dims[0] == 160: monkeypatch.setenv("GNN_MLP_PATH", "generic")
     if wavek is None: monkeypatch.delenv("GNN_MLP_WAVEK", raising=False)
     else: monkeypatch.setenv("GNN_MLP_WAVEK", wavek)
     X, Y = make_batch(dims, B, seed=123, sparse=True)
