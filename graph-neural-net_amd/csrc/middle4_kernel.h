@@ -288,7 +288,8 @@ __device__ __forceinline__ void rowblock_product(const float *A_img, int lda, co
 // and the products run on the same exact-f32 MFMA -- a product of two bf16 values is exact in f32, so this IS bf16
 // operands with f32 accumulation; the kernel is bound by issue and loads, not by the MFMA rate.  Outputs for the
 // tile kernel (A_l, delta_l) are written as bf16.  NSLOT8: static weight slabs of the bf16 staging.
-template <int NL, int ACT_T, int OUTK, bool BACKWARD, bool STAMP, int NSLOT, int NS, bool BF = false, int NSLOT8 = 0>
+// SGV: static shape, the number of slab groups (Mid4Plan::sgrp); 0: read from the plan
+template <int NL, int ACT_T, int OUTK, bool BACKWARD, bool STAMP, int NSLOT, int NS, bool BF = false, int NSLOT8 = 0, int SGV = 0>
 __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     const int ACT = (ACT_T >= 0) ? ACT_T : p.inner_act;
     auto opv = [](float x) { return BF ? bf16_value(x) : x; };  // the value an operand image holds
@@ -314,7 +315,9 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     f32x4 a1v = {0.f, 0.f, 0.f, 0.f};
     const int ns = NS > 0 ? NS : (NS < 0 ? p.n_slabs : 0); // block-uniform
     const int sg = (NS != 0) ? m.sgrp : 1;                 // threads per A_1 element (slab groups)
-    constexpr int NSV = NS > 0 ? NS : (NS < 0 ? MID4_MAX_SLABS : 1); // most slabs one thread may have to take (sg = 1)
+    // most slabs one thread may have to take: with SGV slab groups known at compile time ceil(NS / SGV) (13 slabs on 3 groups:
+    // 5 registers, not 13 -- the unused ones were zeroed again at every scheduling fence below, ~30 instructions of this phase)
+    constexpr int NSV = (NS > 0 && SGV > 0) ? (NS + SGV - 1) / SGV : NS > 0 ? NS : (NS < 0 ? MID4_MAX_SLABS : 1);
     f32x4 zs[NSV];
     // thread -> (element se of the 4 x ld[1]/4 float4s, slab group sgi); with sg = 1 this is (t, 0) for t < 4*q1
     const int sgi = (NS != 0 && sg > 1) ? (NSLOT > 0 ? t / m.ld[1] : (int)(((unsigned)t * m.inv_e) >> 22)) : 0;
@@ -324,13 +327,15 @@ __device__ __forceinline__ void middle4_body(const Mid4Plan &m, Mid4Params &p) {
     if constexpr (NS == 0) {
         a1v = *reinterpret_cast<const f32x4 *>(p.act[1] + (a1_on ? (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4 : (size_t)0));
     } else {
-        const float *zp = p.slabs + (s_on ? (size_t)(row0 + s_r) * m.ld[1] + s_q * 4 : (size_t)0);
-        const size_t sstride = (size_t)p.slab_rows * m.ld[1];
+        // 32-bit element offsets (the slab buffer is far below 2^32 floats: plan_chain checks): a 64-bit product per slab
+        // load was ~7 instructions each in a phase that is bound by instruction issue (16 waves per CU)
+        const unsigned zoff = s_on ? (unsigned)(row0 + s_r) * (unsigned)m.ld[1] + (unsigned)(s_q * 4) : 0u;
+        const unsigned sstride = (unsigned)p.slab_rows * (unsigned)m.ld[1];
 #pragma unroll
         for (int i = 0; i < NSV; i++) {
             const int s_ = sgi + i * sg;
             zs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (s_ < ns) zs[i] = *reinterpret_cast<const f32x4 *>(zp + (s_on ? s_ * sstride : (size_t)0));
+            if (s_ < ns) zs[i] = *reinterpret_cast<const f32x4 *>(p.slabs + (zoff + (s_on ? (unsigned)s_ * sstride : 0u)));
         }
     }
     // this thread's slabs in ascending order; with one thread per element that is the whole sum: then f;
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(1024) void middle4_kernel(Mid4Params p) {
         constexpr Mid4Plan m = SH::template make<BF16>();
         constexpr int ns = SLABS ? (m.ld[0] + 63) / 64 : 0;
         static_assert(ns <= MID4_MAX_SLABS, "too many first-layer slabs for the register-resident sum");
-        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, m.st_total, ns, BF16, m.st8_total>(m, p);
+        middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, m.st_total, ns, BF16, m.st8_total, (ns > 0 ? m.sgrp : 0)>(m, p);
     } else {
         middle4_body<SH::kL, ACT, OUTK, BACKWARD, STAMP, 0, SLABS ? -1 : 0, BF16, 0>(p.plan, p);
     }
