@@ -626,7 +626,7 @@ void plan_chain(gnn_mlp *h) {
     }
     h->ts_tiles = tiles;
     const size_t n = (size_t)h->n_slabs * h->cap_rows * h->ld[1];
-    if (n >= (1ull << 32)) return; // middle4 addresses the slabs with 32-bit element offsets
+    if (n >= (1ull << 30)) return; // middle4 addresses the slabs with 32-bit byte offsets
     if (hipMalloc(reinterpret_cast<void **>(&h->slabs), sizeof(float) * n) != hipSuccess) { (void)hipGetLastError(); h->slabs = nullptr; return; }
     if (hipMemsetAsync(h->slabs, 0, sizeof(float) * n, h->stream) != hipSuccess) { (void)hipGetLastError(); return; }
     t.slabs = h->slabs; t.slab_rows = h->cap_rows; t.ldz = h->ld[1];
