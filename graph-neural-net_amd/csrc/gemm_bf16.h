@@ -76,10 +76,12 @@ constexpr size_t gemm_bf16_lds_bytes() {
     return sizeof(__bf16) * ((A_KC ? BM * LDK : BK * LDTA) + (B_KC ? BN * LDK : BK * LDTB));
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int NSTG = 2>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
+// WM: wave rows (waves are WM x 2, WM * 128 threads); WM = 4 puts eight waves on a tile (see gemm_f32_kernel)
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int NSTG = 2, int WM = 2>
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmBf16Params p) {
+    constexpr int NT = WM * 128;
     constexpr int BK = GemmBf16Depth<BM>::BK;
-    constexpr int TM = BM / 32, TN = BN / 32; // 16x16 MFMA tiles per wave (waves are 2 x 2)
+    constexpr int TM = BM / (WM * 16), TN = BN / 32; // 16x16 MFMA tiles per wave (waves are WM x 2)
     constexpr int LDK = BK + 8;               // k-contiguous image: row stride = 4 banks (mod 64): 16 rows x 2 k-groups of a ds_read_b64 hit 64 banks once
     // k-major image: row stride 32*odd bytes (BM = 128: 288 B, 64: 160 B, 32: 96 B)
     constexpr int LDTA = BM + ((BM / 16) % 2 == 0 ? 16 : 0), LDTB = BN + ((BN / 16) % 2 == 0 ? 16 : 0);
@@ -91,8 +93,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    constexpr int NA = BM * BK / 8 / 256, NB = BN * BK / 8 / 256; // 16-B chunks (8 bf16) per thread per tile
-    static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+    constexpr int NA = BM * BK / 8 / NT, NB = BN * BK / 8 / NT; // 16-B chunks (8 bf16) per thread per tile
+    static_assert(NA >= 1 && NB >= 1 && TM >= 1, "tile too small for this many threads");
     bf16x8 ra0[NA], rb0[NB], ra1[NA], rb1[NB]; // register stages
 
     // interior tiles (wholly inside M x N, K a multiple of BK): unguarded loads through 32-bit element offsets (see gemm_f32_kernel)
@@ -102,12 +104,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     unsigned oa[NA], ob[NB];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
-        const int c = t + i * 256;
+        const int c = t + i * NT;
         oa[i] = A_KC ? (unsigned)(m0 + c / (BK / 8)) * (unsigned)p.lda + (c % (BK / 8)) * 8 : (unsigned)(c / (BM / 8)) * (unsigned)p.lda + m0 + (c % (BM / 8)) * 8;
     }
 #pragma unroll
     for (int i = 0; i < NB; i++) {
-        const int c = t + i * 256;
+        const int c = t + i * NT;
         ob[i] = B_KC ? (unsigned)(n0 + c / (BK / 8)) * (unsigned)p.ldb + (c % (BK / 8)) * 8 : (unsigned)(c / (BN / 8)) * (unsigned)p.ldb + n0 + (c % (BN / 8)) * 8;
     }
     const unsigned a_kstride = A_KC ? 1u : (unsigned)p.lda, b_kstride = B_KC ? 1u : (unsigned)p.ldb;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
         }
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int c = t + i * 256;
+            const int c = t + i * NT;
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (A_KC) {
                 const int row = c / (BK / 8), kq = c % (BK / 8);
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int c = t + i * 256;
+            const int c = t + i * NT;
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (B_KC) {
                 const int row = c / (BK / 8), kq = c % (BK / 8);
@@ -153,13 +155,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     auto store_tiles = [&](const bf16x8 (&ra)[NA], const bf16x8 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int c = t + i * 256;
+            const int c = t + i * NT;
             if (A_KC) *reinterpret_cast<bf16x8 *>(&As[(c / (BK / 8)) * LDK + (c % (BK / 8)) * 8]) = ra[i];
             else *reinterpret_cast<bf16x8 *>(&As[(c / (BM / 8)) * LDTA + (c % (BM / 8)) * 8]) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int c = t + i * 256;
+            const int c = t + i * NT;
             if (B_KC) *reinterpret_cast<bf16x8 *>(&Bs[(c / (BK / 8)) * LDK + (c % (BK / 8)) * 8]) = rb[i];
             else *reinterpret_cast<bf16x8 *>(&Bs[(c / (BN / 8)) * LDTB + (c % (BN / 8)) * 8]) = rb[i];
         }
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     // private LDS area and handles it as 16-B pieces: lane -> (row, 4 consecutive columns), 256-B runs per row.
     constexpr int EW = TN * 16, ELD = EW + 4, C4 = EW / 4, RPP = 64 / C4, PASSES = 16 / RPP; // float4s per row, rows per pass
     float *est = reinterpret_cast<float *>(gemm_bf16_smem) + wave * (16 * ELD);
-    static_assert(4 * 16 * ELD * sizeof(float) <= gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC>(), "epilogue staging fits the operand images");
+    static_assert(2 * WM * 16 * ELD * sizeof(float) <= gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC>(), "epilogue staging fits the operand images");
     const int erow = lane / C4, ec4 = lane % C4;
 #pragma unroll
     for (int i = 0; i < TM; i++) {

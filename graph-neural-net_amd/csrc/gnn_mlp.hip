@@ -270,18 +270,18 @@ void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
 }
 
 // bf16 operands (gemm_bf16.h): the same tile choice; 128x128 tiles only when they alone fill the chip
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2>
 void launch_gemm_bf16_t(gnn_mlp *h, int cls, const GemmBf16Params &p) {
     constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC>();
     static bool opted_in = false; // more than 64 KB of dynamic LDS needs the opt-in, once per instantiation
     if (!opted_in) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, 2, WM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             if (h->launch_error == hipSuccess) h->launch_error = hipGetLastError();
         }
         opted_in = true;
     }
-    launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI>, dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(256), lds, p);
+    launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, 2, WM>, dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(WM * 128), lds, p);
 }
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
@@ -295,7 +295,12 @@ void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
     if (tile == 128 && !A_KC && !B_KC && EPI == EPI_SGD) tile = 64;
     switch (tile) {
     case 128: launch_gemm_bf16_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;
-    case 64: launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI>(h, cls, p); break;
+    case 64:
+        // the forward form gains ~6 % from eight waves on the tile (512 x 2048 x 4096: 28.0 -> 26.3 us); backward data loses
+        // 3-10 %, the gradient form is even (profiles/r02/gemm_probe_bf16_waves.log)
+        if constexpr (A_KC && !B_KC) launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI, 4>(h, cls, p);
+        else launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI>(h, cls, p);
+        break;
     default: launch_gemm_bf16_t<32, 32, A_KC, B_KC, EPI>(h, cls, p); break;
     }
 }

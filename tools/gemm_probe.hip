@@ -85,7 +85,7 @@ void check(int M, int N, int K) {
 }
 
 // bf16 GEMM (gemm_bf16.h) on the same buffers reinterpreted (timing only; values are whatever the bits are)
-template <int BM, int BN, bool AK, bool BKC, int EPI, int NSTG = 2>
+template <int BM, int BN, bool AK, bool BKC, int EPI, int NSTG = 2, int WM = 2>
 void runb(const char *what, int M, int N, int K) {
     GemmBf16Params p{};
     p.A = reinterpret_cast<const __bf16 *>(dA); p.lda = AK ? K : M;
@@ -95,18 +95,18 @@ void runb(const char *what, int M, int N, int K) {
     p.aux = dW; p.ldaux = N; p.W = dW; p.V = dV; p.Wb = reinterpret_cast<__bf16 *>(dAux); p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
     if (EPI == EPI_SGD) { p.C = nullptr; p.Cb = nullptr; }
     constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, AK, BKC>();
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(256);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(WM * 128);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG>), grid, block, lds, 0, p);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG, WM>), grid, block, lds, 0, p);
     CK(hipDeviceSynchronize());
     const int iters = 30;
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG>), grid, block, lds, 0, p);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG, WM>), grid, block, lds, 0, p);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-    printf("%-34s %4dx%4dx%4d  bf16 tile %3dx%-3d stages %d  %8.2f us  %6.1f TFLOP/s (%4.1f %% of 2500)  %d tiles\n", what, M, N, K, BM, BN, NSTG, us, tf, 100.0 * tf / 2500.0,
+    printf("%-34s %4dx%4dx%4d  bf16 tile %3dx%-3d stages %d waves %d  %8.2f us  %6.1f TFLOP/s (%4.1f %% of 2500)  %d tiles\n", what, M, N, K, BM, BN, NSTG, WM * 2, us, tf, 100.0 * tf / 2500.0,
            (int)(grid.x * grid.y));
     fflush(stdout);
 }
@@ -159,24 +159,22 @@ int main(int argc, char **argv) {
     if (which == 10) {
         printf("---- bf16 GEMMs of configs[3] (each twice)\n");
         for (int rep = 0; rep < 2; rep++) {
-            runb<64, 64, true, false, EPI_ACT, 2>("forward 1", 512, 2048, 4096);
-            runb<64, 64, true, false, EPI_ACT, 1>("forward 1", 512, 2048, 4096);
-            runb<64, 64, true, false, EPI_ACT, 2>("forward 2", 512, 2048, 2048);
-            runb<64, 64, true, false, EPI_ACT, 1>("forward 2", 512, 2048, 2048);
-            runb<64, 64, true, false, EPI_STORE, 2>("logits", 512, 1024, 2048);
-            runb<64, 64, true, false, EPI_STORE, 1>("logits", 512, 1024, 2048);
-            runb<64, 64, true, true, EPI_DACT, 2>("backward data 2", 512, 2048, 1024);
-            runb<64, 64, true, true, EPI_DACT, 1>("backward data 2", 512, 2048, 1024);
-            runb<64, 64, true, true, EPI_DACT, 2>("backward data 1", 512, 2048, 2048);
-            runb<64, 64, true, true, EPI_DACT, 1>("backward data 1", 512, 2048, 2048);
-            runb<128, 128, false, false, EPI_SGD, 2>("gradient + update 0", 4096, 2048, 512);
-            runb<128, 128, false, false, EPI_SGD, 1>("gradient + update 0", 4096, 2048, 512);
-            runb<64, 64, false, false, EPI_SGD, 2>("gradient + update 0", 4096, 2048, 512);
-            runb<128, 128, false, false, EPI_SGD, 2>("gradient + update 1", 2048, 2048, 512);
-            runb<64, 64, false, false, EPI_SGD, 2>("gradient + update 1", 2048, 2048, 512);
-            runb<64, 64, false, false, EPI_SGD, 1>("gradient + update 1", 2048, 2048, 512);
-            runb<64, 64, false, false, EPI_SGD, 2>("gradient + update 2", 2048, 1024, 512);
-            runb<64, 64, false, false, EPI_SGD, 1>("gradient + update 2", 2048, 1024, 512);
+            runb<64, 64, true, false, EPI_ACT, 2, 2>("forward 1", 512, 2048, 4096);
+            runb<64, 64, true, false, EPI_ACT, 2, 4>("forward 1", 512, 2048, 4096);
+            runb<64, 64, true, false, EPI_ACT, 2, 2>("forward 2", 512, 2048, 2048);
+            runb<64, 64, true, false, EPI_ACT, 2, 4>("forward 2", 512, 2048, 2048);
+            runb<64, 64, true, false, EPI_STORE, 2, 2>("logits", 512, 1024, 2048);
+            runb<64, 64, true, false, EPI_STORE, 2, 4>("logits", 512, 1024, 2048);
+            runb<64, 64, true, true, EPI_DACT, 2, 2>("backward data 2", 512, 2048, 1024);
+            runb<64, 64, true, true, EPI_DACT, 2, 4>("backward data 2", 512, 2048, 1024);
+            runb<64, 64, true, true, EPI_DACT, 2, 2>("backward data 1", 512, 2048, 2048);
+            runb<64, 64, true, true, EPI_DACT, 2, 4>("backward data 1", 512, 2048, 2048);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 0", 4096, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 0", 4096, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 1", 2048, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 1", 2048, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 2", 2048, 1024, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 2", 2048, 1024, 512);
         }
         return 0;
     }
