@@ -38,7 +38,7 @@ struct DirectReduceParams {
 };
 
 // G = sum_r G_r in rank order (the same order on every replica: identical bits everywhere), then SCE:333-339.
-__global__ __launch_bounds__(256) void direct_reduce_update_kernel(DirectReduceParams p) {
+static __global__ __launch_bounds__(256) void direct_reduce_update_kernel(DirectReduceParams p) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n4; i += (int64_t)gridDim.x * 256) {
         float4 g = p.G[0][i];
 #pragma unroll

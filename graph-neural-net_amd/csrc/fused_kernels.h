@@ -471,7 +471,7 @@ struct TailParams {
 // 16 x K x 16 MACs), split 0 stores them, and each split makes its share of delta_{L-2}'s columns -- 16 workgroups for a
 // 256-row batch became 128, and the column tiles' operands are requested together instead of one dependent round trip per
 // tile (784-1024^3-10 at 256 rows: 12.3 -> see profiles/r02).
-__global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
+static __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
     constexpr int NW = 8, MAXC = 8, RLD = 20;
     __shared__ __attribute__((aligned(16))) float red[NW * 16 * RLD];
     __shared__ __attribute__((aligned(16))) float dl[16 * RLD];

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmBf16Params p) {
 }
 
 // f32 -> bf16 (RNE) over a flat buffer: the shadow of W after set_weights / init / load, dataset rows, ...
-__global__ __launch_bounds__(256) void to_bf16_kernel(const float4 *__restrict__ src, bf16x4 *__restrict__ dst, int64_t n4) {
+static __global__ __launch_bounds__(256) void to_bf16_kernel(const float4 *__restrict__ src, bf16x4 *__restrict__ dst, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 v = src[i];
         dst[i] = (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};

@@ -1,0 +1,257 @@
+// handle.h -- internal: the handle behind gnn_mlp_t, the error convention, and the functions the
+// translation units of the library call in each other (abi / plan / launch_* / checkpoint / sampler / dp).
+// Nothing here is part of the C ABI (include/gnn_mlp.h).
+#pragma once
+#include "../../include/gnn_mlp.h"
+#include "fused_kernels.h"
+#include "gemm_bf16.h"
+#include "gemm_wavek.h"
+#include "middle4_kernel.h"
+#include "tile_step_kernel.h"
+#include "kernels.h"
+
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+struct TimerClass {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+};
+
+struct gnn_mlp {
+    int device = 0;
+    int L = 0;                 // layerDims.length
+    std::vector<int> dims, ld; // logical / padded widths
+    std::vector<size_t> w_off; // offset of W_l in the flat padded buffers
+    int64_t n_params = 0;      // unpadded
+    int64_t n_pad = 0;         // padded flat length
+    int out_kind = 0, inner_act = 0, last_act = 0, loss = 0, dtype = 0;
+    int max_batch = 0, cap_rows = 0;
+    int time = 0;
+
+    float *W = nullptr, *V = nullptr, *G_own = nullptr, *G = nullptr;
+    std::vector<float *> act;   // act[l] = f(z_l), l = 0..L-2 ; act[0] = f(x)
+    std::vector<float *> delta; // delta[l] = dE/dz_l, l = 1..L-1
+    float *logits = nullptr, *prob = nullptr, *ybuf = nullptr, *lossv = nullptr;
+    int32_t *labels = nullptr, *idxbuf = nullptr;
+    double *stage_x = nullptr, *stage_y = nullptr, *stage_out = nullptr;
+
+    float *DX = nullptr, *DY = nullptr; // device-resident dataset (A_0 = f(x) and y)
+    // GNN_DTYPE_BF16 (gemm_bf16.h): bf16 roundings of every GEMM operand, written once by its producer
+    __bf16 *Wb = nullptr;               // shadow of W, same padded layout
+    std::vector<__bf16 *> actb, deltab; // actb[l] l = 0..L-2, deltab[l] l = 1..L-1
+    __bf16 *DXb = nullptr;              // dataset inputs
+    int64_t dataset_n = 0;
+
+    hipStream_t stream = nullptr, own_stream = nullptr;
+
+    // fused small-net path (fused_kernels.h): plan made once at create
+    bool fused = false;
+    gnn::GradParams grad{};
+    int grad_tiles = 0;
+    gnn::GradParams grad64{};      // the same layers cut into 64x64 tiles (grad_update64_kernel), used when grad_tiles is large
+    int grad_tiles64 = 0;
+    bool mid_generic = false; // middle weights exceed LDS: per-layer GEMMs, fwd_first / grad_update chosen per call (hybrid_choice)
+    bool mid4 = false;        // middle4_kernel: every middle weight matrix resident in LDS
+    gnn::Mid4Params mid4p{};
+    size_t mid4_lds_bytes = 0;
+    const void *mid4_fn[3] = {nullptr, nullptr, nullptr}; // forward only / forward + backward / the same with A_1 from K slabs
+                                                          // (bf16 nets: only slot 2, the bf16 training kernel)
+    hipFunction_t mid4_jit[3] = {nullptr, nullptr, nullptr}; // run-time instantiation (jit.h), preferred when set
+
+    // two-launch step (tile_step_kernel.h): the tile kernel of step s also makes the first-layer K slabs of step s+1
+    bool chain = false;
+    gnn::TileStepParams tsp{};
+    int ts_tiles = 0, ts_tiles0 = 0; // blocks of all layers / of layer 0 alone
+    float *slabs = nullptr;
+    int n_slabs = 0;
+    // the batch whose first-layer sums (for the CURRENT weights) the slabs hold
+    bool slab_valid = false; const float *slab_a0 = nullptr; const int32_t *slab_idx = nullptr; int slab_B = 0;
+    // the batch the next gradient computation will run on (gnn_mlp_hint_next_range, train loops); consumed by the
+    // next kernel that updates the weights
+    bool have_next = false; const float *next_a0 = nullptr; const int32_t *next_idx = nullptr; int next_B = 0;
+    // contiguous copies of SAMPLED batches (two, used alternately): the tile kernel that forms a sampled batch's slabs also
+    // writes the rows it gathered; the next step's gradient product reads them in place of the index-gathered rows
+    float *xstage[2] = {nullptr, nullptr}; __bf16 *xstage_b[2] = {nullptr, nullptr};
+    int xstage_cur = 0; bool xstage_valid = false; // xstage[xstage_cur] holds the rows of the batch the slabs describe
+    int specialization = 0;   // 0 runtime-shape kernels, 1 prebuilt static shape, 2 run-time instantiation
+    bool jit_tried = false;
+    int steps_seen = 0;       // gradient computations so far: the 16th triggers the specialisation
+
+    // train_range graph: one pass over the dataset's batches captured once, replayed many times
+    hipGraphExec_t tr_exec = nullptr;
+    hipGraph_t tr_graph = nullptr;
+    int64_t tr_first_batch = -1; int tr_B = 0; int64_t tr_nb = 0; double tr_step = 0, tr_mom = 0;
+    const float *tr_dx = nullptr;
+
+    hipError_t launch_error = hipSuccess; // first refused launch of a module / function-pointer kernel since the last check
+    const int32_t *cur_idx = nullptr; // device row indices of the batch being stepped (fused path reads rows through them)
+
+    bool timing = false;
+    TimerClass timers[5];
+
+    // development / test switches, read ONCE at create (never on the step path)
+    int env_path = 0;          // GNN_MLP_PATH: 0 default, 1 "generic", 2 "nomid4"
+    int env_hybrid = -1;       // GNN_MLP_HYBRID: -1 unset, else bit 0 = fwd_first, bit 1 = grad_update
+    bool env_tail_off = false; // GNN_MLP_TAIL=0: the three-launch form instead of tail_kernel
+    bool env_wavek_off = false; // GNN_MLP_WAVEK=0: gemm_f32_kernel<32, 32> instead of the wave-K kernel (development)
+    bool env_graph = false;    // GNN_MLP_GRAPH=1: train_range replays a captured pass
+    bool env_jit_off = false;  // GNN_MLP_JIT=0
+    bool env_static_off = false; // GNN_MLP_STATIC=0
+    bool env_chain_off = false;  // GNN_MLP_CHAIN=0: three launches per step (fwd_first / middle4 / grad_update)
+};
+
+namespace gnn {
+namespace host {
+
+// ---- error convention (abi.hip) ---------------------------------------------------------------
+int fail(int code, const std::string &msg);   // records the calling thread's message, returns `code`
+const char *last_error_message();
+int check_launches(gnn_mlp *h);
+int check_handle(const gnn_mlp *h);
+int check_batch(const gnn_mlp *h, int B);
+int check_range(const gnn_mlp *h, int64_t first, int B);
+int check_step_args(gnn_mlp *h, int B, double step, int noise);
+int get_flat(gnn_mlp *h, const float *dev, double *flat);
+int set_flat(gnn_mlp *h, float *dev, const double *flat);
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ::gnn::host::fail(GNN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define TRY_LAUNCHES(h)                              \
+    do {                                             \
+        int rc_ = ::gnn::host::check_launches(h);    \
+        if (rc_ != GNN_OK) return rc_;               \
+    } while (0)
+#define TRY(expr)                      \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != GNN_OK) return rc_; \
+    } while (0)
+
+inline int grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+// ---- timing ---------------------------------------------------------------------------
+struct ScopedTimer {
+    gnn_mlp *h; int cls; bool on = false; size_t slot = 0;
+    ScopedTimer(gnn_mlp *h_, int c) : h(h_), cls(c) {
+        if (!h->timing) return;
+        TimerClass &t = h->timers[cls];
+        if (t.used >= 8192) return;
+        if (t.used >= t.start.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            t.start.push_back(a); t.stop.push_back(b);
+        }
+        slot = t.used++;
+        on = true;
+        (void)hipEventRecord(t.start[slot], h->stream);
+    }
+    ~ScopedTimer() {
+        if (on) (void)hipEventRecord(h->timers[cls].stop[slot], h->stream);
+    }
+};
+
+// Launch with the dispatch's OWN begin/end timestamps (hipExtLaunchKernel start/stop events): the
+// elapsed time between them is the kernel's execution time, the same quantity rocprofv3's
+// kernel trace reports -- unlike events recorded around a launch, which add marker overhead.
+template <class K, class P> void launch_timed(gnn_mlp *h, int cls, K kernel, dim3 grid, dim3 block, size_t lds, const P &params) {
+    if (h->timing && cls >= 0) {
+        TimerClass &t = h->timers[cls];
+        if (t.used < 8192) {
+            if (t.used >= t.start.size()) {
+                hipEvent_t a = nullptr, b = nullptr;
+                if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { t.start.push_back(a); t.stop.push_back(b); }
+            }
+            if (t.used < t.start.size()) {
+                const size_t slot = t.used++;
+                hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, h->stream, t.start[slot], t.stop[slot], 0, params);
+                return;
+            }
+        }
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, h->stream, params);
+}
+
+// Zero-filled device allocation.  The fill is enqueued on the HANDLE's stream: that stream is
+// non-blocking, so a legacy-stream hipMemset would not be ordered with the kernels that follow.
+template <typename T> int dev_alloc(T **p, size_t n, hipStream_t s) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), sizeof(T) * (n ? n : 1)));
+    HIP_TRY(hipMemsetAsync(*p, 0, sizeof(T) * (n ? n : 1), s));
+    return GNN_OK;
+}
+
+// scratch device allocation released on every exit path
+struct DevScratch {
+    void *p = nullptr;
+    ~DevScratch() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        HIP_TRY(hipMalloc(&p, bytes ? bytes : 1));
+        return GNN_OK;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// ---- launch_gemm.hip: per-layer f32 GEMMs and the three-launch small-net kernels -----------------
+int pick_tile(int M, int N);
+bool wavek_fits(int M, int N, int K);
+void forward(gnn_mlp *h, const float *a0, int B, int first_l = 1, bool stop_before_last = false);
+void run_output(gnn_mlp *h, const float *y, int B, bool want_prob, bool want_delta, bool want_loss, bool want_label);
+void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_over_b, float momentum,
+              bool data_only = false, bool have_last_delta = false);
+void launch_fwd_first(gnn_mlp *h, const float *a0, int B);
+void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_over_b, float momentum);
+void launch_tail(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob, bool want_loss, bool want_label);
+
+// ---- launch_bf16.hip ---------------------------------------------------------------------------
+void forward_bf16(gnn_mlp *h, const __bf16 *a0b, int B);
+void backward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool fused_update, float step_over_b, float momentum);
+void to_bf16(gnn_mlp *h, const float *src, __bf16 *dst, size_t n);
+
+// ---- launch_small.hip: the row-block kernel and the tile-owner kernel ----------------------------
+struct NextBatch { const float *a0; const int32_t *idx; int B; };
+void plan_mid4(gnn_mlp *h);
+void try_specialize(gnn_mlp *h);
+void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
+                   bool want_loss, bool want_label, bool from_slabs = false);
+void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, const float *a0, int B, float step_over_b, float momentum,
+                      bool staged = false);
+
+// ---- launch_misc.hip: encodings, gathers, the flat update ---------------------------------------
+void launch_convert_rows(gnn_mlp *h, const double *src, int d, float *dst, int ld, int64_t rows, int64_t rows_pad, int act, int apply_act);
+void launch_encode_u8(gnn_mlp *h, const uint8_t *pix, int d, float *dst, int ld, int64_t rows, int act);
+void launch_onehot_u8(gnn_mlp *h, const uint8_t *lab, int n_classes, float *dst, int ld, int64_t rows);
+int stage_rows(gnn_mlp *h, const double *src, int d, int ld, int B, double *stage, float *dst, bool apply_act);
+int export_rows(gnn_mlp *h, const float *src, int ld, int d, int B, double *host_dst);
+void launch_gather(gnn_mlp *h, const int32_t *d_idx, int B);
+void launch_flat_update(gnn_mlp *h, int B_global, double step, double momentum);
+
+// ---- plan.hip: which kernels a net takes, and one step made of them -------------------------------
+void plan_fused(gnn_mlp *h);
+void plan_chain(gnn_mlp *h);
+const __bf16 *a0_bf16(const gnn_mlp *h, const float *a0);
+bool slabs_hold(const gnn_mlp *h, const float *a0, const int32_t *idx, int B);
+bool take_next(gnn_mlp *h, NextBatch *nb);
+void slabs_now_hold(gnn_mlp *h, const NextBatch &nb, bool staged_copy = false);
+void hint_range(gnn_mlp *h, int64_t row0, int B);
+void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_prob, bool want_loss, bool want_label);
+void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum,
+                 bool resident = false);
+void maybe_specialize(gnn_mlp *h);
+int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step, double momentum, bool resident);
+int step_on_device_indices(gnn_mlp *h, const int32_t *d_idx, int B, double step, double momentum);
+
+} // namespace host
+} // namespace gnn

@@ -402,7 +402,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
+static __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.B_pad) return;
@@ -555,7 +555,7 @@ struct SgdParams {
     float step_over_b, momentum;
     sgd_bf16x4 *Wb; // bf16 mode: the shadow of W (may be null)
 };
-__global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdParams p) {
+static __global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdParams p) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n4; i += (int64_t)gridDim.x * 256) {
         const float4 g = p.G[i];
         float4 v = p.V[i], w = p.W[i];
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdParams p) {
 // Input encoding.  Host fp64 rows -> padded f32 rows; apply_act: the reference applies the
 // inner activation to the raw input too (SCE:183-186 with l-1 = 0), so A_0 = f(x).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void convert_rows_f64_kernel(const double *__restrict__ src, int d,
+static __global__ __launch_bounds__(256) void convert_rows_f64_kernel(const double *__restrict__ src, int d,
                                                               float *__restrict__ dst, int ld, int64_t rows,
                                                               int64_t rows_pad, int act, int apply_act) {
     const int64_t total = rows_pad * ld;
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void convert_rows_f64_kernel(const double *__r
 }
 
 // raw IDX bytes -> A_0 = f(pixel/255.0) (MT:98) and one-hot labels (MT:112-118)
-__global__ __launch_bounds__(256) void encode_u8_kernel(const uint8_t *__restrict__ pix, int d,
+static __global__ __launch_bounds__(256) void encode_u8_kernel(const uint8_t *__restrict__ pix, int d,
                                                        float *__restrict__ dst, int ld, int64_t rows,
                                                        int64_t rows_pad, int act) {
     const int64_t total = rows_pad * ld;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void encode_u8_kernel(const uint8_t *__restric
         dst[i] = v;
     }
 }
-__global__ __launch_bounds__(256) void onehot_u8_kernel(const uint8_t *__restrict__ lab, int n_classes,
+static __global__ __launch_bounds__(256) void onehot_u8_kernel(const uint8_t *__restrict__ lab, int n_classes,
                                                        float *__restrict__ dst, int ld, int64_t rows,
                                                        int64_t rows_pad) {
     const int64_t total = rows_pad * ld;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void onehot_u8_kernel(const uint8_t *__restric
 
 // gather dataset rows by index (one NNT.sample draw, NNT:143-158) into a dense batch
 // rows idx[0..B) of TWO row-aligned matrices (inputs and expected outputs) in one launch
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src_x, int ld_x, float *__restrict__ dst_x,
+static __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src_x, int ld_x, float *__restrict__ dst_x,
                                                          const float *__restrict__ src_y, int ld_y, float *__restrict__ dst_y,
                                                          const int32_t *__restrict__ idx, int B, int B_pad) {
     const int x4 = ld_x / 4, y4 = ld_y / 4, row4 = x4 + y4;
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
 }
 
 // f32 rows (padded) -> host-bound fp64 rows (unpadded)
-__global__ __launch_bounds__(256) void export_rows_f64_kernel(const float *__restrict__ src, int ld, int d,
+static __global__ __launch_bounds__(256) void export_rows_f64_kernel(const float *__restrict__ src, int ld, int d,
                                                              int64_t rows, double *__restrict__ dst) {
     const int64_t total = rows * d;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {

@@ -1,0 +1,109 @@
+// launch_bf16.hip -- host side of GNN_DTYPE_BF16's per-layer GEMMs (gemm_bf16.h).
+#include "handle.h"
+
+using namespace gnn;
+using namespace gnn::host;
+
+namespace gnn {
+namespace host {
+
+// bf16 operands (gemm_bf16.h): the same tile choice; 128x128 tiles only when they alone fill the chip
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2>
+void launch_gemm_bf16_t(gnn_mlp *h, int cls, const GemmBf16Params &p) {
+    constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC>();
+    static bool opted_in = false; // more than 64 KB of dynamic LDS needs the opt-in, once per instantiation
+    if (!opted_in) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, 2, WM>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            if (h->launch_error == hipSuccess) h->launch_error = hipGetLastError();
+        }
+        opted_in = true;
+    }
+    launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, 2, WM>, dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(WM * 128), lds, p);
+}
+template <bool A_KC, bool B_KC, int EPI>
+void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
+    // bytes per MAC fall with the tile edge and these kernels are bound by operand traffic per CU, so 64 x 64 tiles
+    // already from 128 tiles up (f32 wants 256): the 512 x 1024 logits of 4096-2048-2048-1024 took 13.5 us on 32 x 32 tiles
+    int tile = pick_tile(p.M, p.N);
+    if (tile == 32 && (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64) >= 128) tile = 64;
+    // the gradient form with the update is bound by the masters' traffic in its epilogue, and there more, smaller workgroups
+    // keep more of it in flight: 4096 x 2048 x 512 with the update 41.5 us on 128 x 128 tiles (one workgroup per CU at its
+    // register count), 32.4 us on 64 x 64 (profiles/r02/gemm_probe_bf16_interior.log)
+    if (tile == 128 && !A_KC && !B_KC && EPI == EPI_SGD) tile = 64;
+    switch (tile) {
+    case 128: launch_gemm_bf16_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;
+    case 64:
+        // the forward form gains ~6 % from eight waves on the tile (512 x 2048 x 4096: 28.0 -> 26.3 us); backward data loses
+        // 3-10 %, the gradient form is even (profiles/r02/gemm_probe_bf16_waves.log)
+        if constexpr (A_KC && !B_KC) launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI, 4>(h, cls, p);
+        else launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI>(h, cls, p);
+        break;
+    default: launch_gemm_bf16_t<32, 32, A_KC, B_KC, EPI>(h, cls, p); break;
+    }
+}
+
+// ---- bf16 mode: forward / backward over the bf16 operand copies -------------------------------------
+void forward_bf16(gnn_mlp *h, const __bf16 *a0b, int B) {
+    const int B_pad = pad_up(B);
+    const __bf16 *in = a0b;
+    for (int l = 1; l < h->L; l++) {
+        GemmBf16Params p{};
+        p.A = in; p.lda = h->ld[l - 1];
+        p.B = h->Wb + h->w_off[l - 1]; p.ldb = h->ld[l];
+        p.M = B_pad; p.N = h->ld[l]; p.K = h->ld[l - 1];
+        p.m_true = B; p.n_true = h->dims[l];
+        p.act = h->inner_act;
+        p.ldc = h->ld[l];
+        if (l < h->L - 1) {
+            p.C = h->act[l]; p.Cb = h->actb[l];
+            launch_gemm_bf16<true, false, EPI_ACT>(h, l == 1 ? GNN_K_FWD_GEMM0 : -1, p);
+            in = h->actb[l];
+        } else {
+            p.C = h->logits; p.Cb = nullptr;
+            launch_gemm_bf16<true, false, EPI_STORE>(h, l == 1 ? GNN_K_FWD_GEMM0 : -1, p);
+        }
+    }
+}
+
+void backward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool fused_update, float step_over_b, float momentum) {
+    const int B_pad = pad_up(B);
+    for (int l = h->L - 2; l >= 0; l--) {
+        if (l >= 1) { // delta_l = (delta_{l+1} . W_l^T) * f'(z_l)   -- before W_l is touched
+            GemmBf16Params p{};
+            p.A = h->deltab[l + 1]; p.lda = h->ld[l + 1];
+            p.B = h->Wb + h->w_off[l]; p.ldb = h->ld[l + 1];
+            p.C = h->delta[l]; p.Cb = h->deltab[l]; p.ldc = h->ld[l];
+            p.M = B_pad; p.N = h->ld[l]; p.K = h->ld[l + 1];
+            p.m_true = B; p.n_true = h->dims[l];
+            p.aux = h->act[l]; p.ldaux = h->ld[l];
+            p.act = h->inner_act;
+            launch_gemm_bf16<true, true, EPI_DACT>(h, -1, p);
+        }
+        GemmBf16Params g{}; // G_l = A_l^T . delta_{l+1}
+        g.A = (l == 0) ? a0b : h->actb[l]; g.lda = h->ld[l];
+        g.B = h->deltab[l + 1]; g.ldb = h->ld[l + 1];
+        g.ldc = h->ld[l + 1];
+        g.M = h->ld[l]; g.N = h->ld[l + 1]; g.K = B_pad;
+        g.m_true = h->dims[l]; g.n_true = h->dims[l + 1];
+        const int cls = (l == 0) ? GNN_K_GRAD_GEMM0 : -1;
+        if (fused_update) {
+            g.W = h->W + h->w_off[l]; g.V = h->V + h->w_off[l]; g.Wb = h->Wb + h->w_off[l];
+            g.step_over_b = step_over_b; g.momentum = momentum;
+            launch_gemm_bf16<false, false, EPI_SGD>(h, cls, g);
+        } else {
+            g.C = h->G + h->w_off[l];
+            launch_gemm_bf16<false, false, EPI_STORE>(h, cls, g);
+        }
+    }
+}
+
+// f32 rows -> their bf16 rounding (n floats, a multiple of 4)
+void to_bf16(gnn_mlp *h, const float *src, __bf16 *dst, size_t n) {
+    const int64_t n4 = (int64_t)(n / 4);
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(grid_for(n4)), dim3(256), 0, h->stream, reinterpret_cast<const float4 *>(src),
+                       reinterpret_cast<bf16x4 *>(dst), n4);
+}
+
+} // namespace host
+} // namespace gnn

@@ -1,0 +1,194 @@
+// launch_small.hip -- host side of the small-net path: the row-block kernel (middle4_kernel.h, with its run-time
+// instantiation, jit.h) and the tile-owner kernel (tile_step_kernel.h).
+#include "handle.h"
+#include "jit.h"
+
+using namespace gnn;
+using namespace gnn::host;
+
+namespace gnn {
+namespace host {
+
+// ---- middle4_kernel plan ----------------------------------------------------------------------
+// kernel table: [shape policy][activation][output kind][backward]
+// variant: 0 forward only, 1 forward + backward, 2 forward + backward with A_1 from the K slabs of tile_step_kernel
+template <class SH, int OUTK> const void *mid4_fn_sh(int act, int variant) {
+#define GNN_M4(A) (variant == 3 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true, false, true, true>) \
+                   : variant == 2 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true, false, true>)  \
+                   : variant == 1 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true>)             \
+                                  : reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, false>))
+    switch (act) {
+    case 0: return GNN_M4(0);
+    case 1: return GNN_M4(1);
+    case 2: return GNN_M4(2);
+    case 3: return GNN_M4(3);
+    default: return GNN_M4(4);
+    }
+#undef GNN_M4
+}
+// shapes with compile-time plans (BASELINE.json configs that take the fused path)
+using ShapeMnistA = StaticShape<784, 300, 100, 10>;
+using ShapeMnistB = StaticShape<784, 100, 50, 10>;
+
+template <class SH> bool shape_matches(const gnn_mlp *h) {
+    constexpr int n = (int)(sizeof(SH::kDims) / sizeof(int));
+    if (h->L != n) return false;
+    for (int i = 0; i < n; i++) if (h->dims[i] != SH::kDims[i]) return false;
+    return true;
+}
+
+const void *mid4_function(const gnn_mlp *h, int variant) {
+    const bool allow_static = !h->env_static_off;
+    if (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE) {
+        if (shape_matches<ShapeMnistA>(h)) return mid4_fn_sh<ShapeMnistA, 0>(h->inner_act, variant);
+        if (shape_matches<ShapeMnistB>(h)) return mid4_fn_sh<ShapeMnistB, 0>(h->inner_act, variant);
+    }
+    // runtime extents: layer count templated (3..6, else generic), activation read from the arguments
+#define GNN_M4RO(NL, OK) (variant == 3 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true, false, true, true>) \
+                          : variant == 2 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true, false, true>) \
+                          : variant == 1 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true>)           \
+                                         : reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, false>))
+#define GNN_M4R(NL) (h->out_kind == GNN_OUT_SOFTMAX_CE ? GNN_M4RO(NL, 0) : GNN_M4RO(NL, 1))
+    switch (h->L) {
+    case 3: return GNN_M4R(3);
+    case 4: return GNN_M4R(4);
+    case 5: return GNN_M4R(5);
+    case 6: return GNN_M4R(6);
+    default: return GNN_M4R(0);
+    }
+#undef GNN_M4R
+#undef GNN_M4RO
+}
+
+void plan_mid4(gnn_mlp *h) {
+    h->mid4 = false;
+    if (h->env_path == 2) return; // tests: force the per-layer middle
+    const int L = h->L, Lm = L - 1;
+    Mid4Params &m = h->mid4p;
+    m = Mid4Params{};
+    const bool bf16 = h->dtype == GNN_DTYPE_BF16;
+    m.plan = make_mid4_plan(h->dims.data(), L, bf16);
+    if (!m.plan.ok) return;
+    h->mid4_lds_bytes = (size_t)m.plan.lds_floats * sizeof(float);
+    for (int l = 1; l < Lm; l++) { m.W[l] = h->W + h->w_off[l]; m.act[l] = h->act[l]; }
+    for (int l = 1; l <= Lm; l++) m.delta[l] = h->delta[l];
+    if (bf16) {
+        for (int l = 1; l < Lm; l++) { m.Wb[l] = h->Wb + h->w_off[l]; m.actb[l] = h->actb[l]; }
+        for (int l = 1; l <= Lm; l++) m.deltab[l] = h->deltab[l];
+    }
+    m.last_act = h->last_act;
+    m.inner_act = h->inner_act;
+    {
+        const bool allow_static = !h->env_static_off;
+        h->specialization = (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE &&
+                             (shape_matches<ShapeMnistA>(h) || shape_matches<ShapeMnistB>(h))) ? 1 : 0;
+    }
+    for (int bwd = (bf16 ? 2 : 0); bwd < 3; bwd++) {
+        h->mid4_fn[bwd] = mid4_function(h, (bf16 && bwd == 2) ? 3 : bwd);
+        if (hipFuncSetAttribute(h->mid4_fn[bwd], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)h->mid4_lds_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+    }
+    h->mid4 = true;
+}
+
+// Run-time instantiation of middle4_kernel for this net's shape (jit.h); silent no-op when the
+// net is already specialised, does not take the middle4 path, or hiprtc is unavailable.
+void try_specialize(gnn_mlp *h) {
+    if (!h->mid4 || h->specialization != 0 || h->jit_tried) return;
+    h->jit_tried = true;
+    if (h->env_jit_off) return;
+    const jit::Specialised *sp = jit::get_middle4(h->device, h->dims.data(), h->L, h->inner_act, h->out_kind, h->chain,
+                                                  h->dtype == GNN_DTYPE_BF16, h->mid4_lds_bytes);
+    if (!sp) return;
+    h->mid4_jit[0] = sp->fn[0];
+    h->mid4_jit[1] = sp->fn[1];
+    h->mid4_jit[2] = sp->fn[2];
+    h->specialization = 2;
+}
+
+// forward of the middle4 path; backward = also delta_1..delta_{L-1}
+// from_slabs: A_1 = f(sum of the K slabs) (tile_step_kernel made them); else fwd_first_kernel writes act[1] first
+void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
+                   bool want_loss, bool want_label, bool from_slabs) {
+    if (!from_slabs) launch_fwd_first(h, a0, B);
+    {
+        Mid4Params m4 = h->mid4p;
+        m4.slabs = h->slabs; m4.slab_rows = h->cap_rows; m4.n_slabs = h->n_slabs;
+        m4.Y = y; m4.ldy = h->ld[h->L - 1];
+        m4.prob = want_prob ? h->prob : nullptr;
+        m4.loss = want_loss ? h->lossv : nullptr;
+        m4.label = want_label ? h->labels : nullptr;
+        m4.B = B;
+        m4.row_idx = h->cur_idx;
+        void *args[] = {&m4};
+        // every padded row is processed: rows >= B become zeros
+        const int bw = from_slabs ? 2 : backward ? 1 : 0;
+        const unsigned grid = (unsigned)(pad_up(B) / 4);
+        TimerClass &tc = h->timers[GNN_K_MIDDLE];
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (h->timing && tc.used < 8192) {
+            if (tc.used >= tc.start.size()) {
+                hipEvent_t a = nullptr, b = nullptr;
+                if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { tc.start.push_back(a); tc.stop.push_back(b); }
+            }
+            if (tc.used < tc.start.size()) { ev0 = tc.start[tc.used]; ev1 = tc.stop[tc.used]; tc.used++; }
+        }
+        hipError_t le;
+        if (h->mid4_jit[bw]) { // module function: global size is given in threads
+            le = hipExtModuleLaunchKernel(h->mid4_jit[bw], grid * 1024u, 1, 1, 1024, 1, 1, h->mid4_lds_bytes, h->stream, args,
+                                          nullptr, ev0, ev1, 0);
+        } else if (ev0) {
+            le = hipExtLaunchKernel(const_cast<void *>(h->mid4_fn[bw]), dim3(grid), dim3(1024), args, h->mid4_lds_bytes,
+                                    h->stream, ev0, ev1, 0);
+        } else {
+            le = hipLaunchKernel(h->mid4_fn[bw], dim3(grid), dim3(1024), args, h->mid4_lds_bytes, h->stream);
+        }
+        // a refused launch must not pass for a step: callers read it back through hipGetLastError / launch_error
+        if (le != hipSuccess && h->launch_error == hipSuccess) h->launch_error = le;
+    }
+}
+
+// ---- tile_step_kernel launches ------------------------------------------------------------------
+// gsrc / gdst / fwd as in tile_step_kernel.h; fwd_only_layer0: the grid covers layer 0's tiles only
+// staged: the current batch's rows come from the contiguous copy xstage[xstage_cur] instead of (a0, cur_idx)
+void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, const float *a0, int B, float step_over_b, float momentum,
+                      bool staged) {
+    TileStepParams t = h->tsp;
+    t.layer[0].A = staged ? h->xstage[h->xstage_cur] : a0;
+    for (int l = 0; l < t.n_layers; l++) t.layer[l].G = h->G + h->w_off[l];
+    t.K = pad_up(B); t.k_true = B;
+    t.row_idx = staged ? nullptr : h->cur_idx;
+    const int stage_dst = h->xstage_cur ^ 1; // a sampled next batch is copied to the OTHER buffer (this launch may be reading the current one)
+    if (next && next->idx) { t.stage_out = h->xstage[stage_dst]; t.stage_out_b = h->xstage_b[stage_dst]; }
+    t.step_over_b = step_over_b; t.momentum = momentum;
+    const bool fwd = next != nullptr;
+    if (fwd) { t.An = next->a0; t.ldan = h->ld[0]; t.next_idx = next->idx; t.next_rows = next->B; t.next_K = pad_up(next->B); }
+    const bool fwd_only = gsrc == 0;
+    const dim3 grid(fwd_only ? h->ts_tiles0 : h->ts_tiles), block(TS_THREADS);
+    if (fwd_only) t.n_layers = 1;
+    const int cls = fwd_only ? GNN_K_FWD_GEMM0 : gsrc == 2 ? GNN_K_UPDATE : GNN_K_GRAD_GEMM0;
+    if (h->dtype == GNN_DTYPE_BF16) {
+        if (staged) t.Ab[0] = h->xstage_b[h->xstage_cur];
+        else if (a0) t.Ab[0] = a0_bf16(h, a0);
+        if (fwd) t.Anb = a0_bf16(h, next->a0);
+        if (fwd_only) launch_timed(h, cls, tile_step_bf16_kernel<0, 0, true>, grid, block, 0, t);
+        else if (gsrc == 1 && gdst == 1) launch_timed(h, cls, tile_step_bf16_kernel<1, 1, false>, grid, block, 0, t);
+        else if (gsrc == 1 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_bf16_kernel<1, 2, false>, grid, block, 0, t);
+        else if (gsrc == 1 && gdst == 2 && fwd) launch_timed(h, cls, tile_step_bf16_kernel<1, 2, true>, grid, block, 0, t);
+        else if (gsrc == 2 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_bf16_kernel<2, 2, false>, grid, block, 0, t);
+        else launch_timed(h, cls, tile_step_bf16_kernel<2, 2, true>, grid, block, 0, t);
+        return;
+    }
+    if (fwd_only) launch_timed(h, cls, tile_step_kernel<0, 0, true>, grid, block, 0, t);
+    else if (gsrc == 1 && gdst == 1) launch_timed(h, cls, tile_step_kernel<1, 1, false>, grid, block, 0, t);
+    else if (gsrc == 1 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_kernel<1, 2, false>, grid, block, 0, t);
+    else if (gsrc == 1 && gdst == 2 && fwd) launch_timed(h, cls, tile_step_kernel<1, 2, true>, grid, block, 0, t);
+    else if (gsrc == 2 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_kernel<2, 2, false>, grid, block, 0, t);
+    else launch_timed(h, cls, tile_step_kernel<2, 2, true>, grid, block, 0, t);
+}
+
+} // namespace host
+} // namespace gnn

@@ -1,0 +1,284 @@
+// plan.hip -- which kernels a net takes (decided once at gnn_mlp_create) and one gradientStep (SCE:297-346) made of
+// them: forward GEMM chain / row-block kernel, output rule, backward data, weight gradient with the momentum update
+// fused in (single GPU) or written to the flat gradient buffer (data parallel).  Host logic only: the launches are in
+// launch_*.hip.
+#include "handle.h"
+
+#include <algorithm>
+
+using namespace gnn;
+using namespace gnn::host;
+
+namespace gnn {
+namespace host {
+
+// Decides whether the net fits the fused path and lays out the middle kernel's LDS.
+void plan_fused(gnn_mlp *h) {
+    h->fused = false;
+    h->mid4 = false;
+    h->mid_generic = false;
+    if (h->env_path == 1) return;
+    const int L = h->L, Lm = L - 1;
+    if (L < 3 || L > MAX_LAYERS) return;
+    if (h->dtype != GNN_DTYPE_F32) {
+        // bf16 operands: per-layer GEMMs (gemm_bf16.h) for inference and for nets off the row-block path; training
+        // of a net that fits the row-block kernel takes the two-launch path in bf16 (tile_step_bf16_kernel + the bf16
+        // instance of middle4_kernel)
+        plan_mid4(h);
+        if (h->mid4) plan_chain(h);
+        if (!h->chain) h->mid4 = false;
+        return;
+    }
+    // gradient tiles: every layer's 32x32 tiles in one grid (shared by both middle kernels)
+    {
+        GradParams &g = h->grad;
+        g = GradParams{};
+        g.n_layers = L - 1;
+        int tiles = 0;
+        for (int l = 0; l < L - 1; l++) {
+            GradLayer &gl = g.layer[l];
+            gl.A = h->act[l]; gl.lda = h->ld[l];
+            gl.D = h->delta[l + 1]; gl.ldd = h->ld[l + 1];
+            gl.W = h->W + h->w_off[l]; gl.V = h->V + h->w_off[l]; gl.G = h->G + h->w_off[l];
+            gl.M = h->ld[l]; gl.N = h->ld[l + 1];
+            gl.tiling = make_xcd_tiling((gl.M + 31) / 32, (gl.N + 31) / 32);
+            gl.block_begin = tiles;
+            tiles += gl.tiling.blocks();
+        }
+        h->grad_tiles = tiles;
+        GradParams &g64 = h->grad64;
+        g64 = g;
+        int tiles64 = 0;
+        for (int l = 0; l < L - 1; l++) {
+            GradLayer &gl = g64.layer[l];
+            gl.tiling = make_xcd_tiling((gl.M + 63) / 64, (gl.N + 63) / 64);
+            gl.block_begin = tiles64;
+            tiles64 += gl.tiling.blocks();
+        }
+        h->grad_tiles64 = tiles64;
+    }
+    // preferred: 4-row blocks with LDS-resident middle weights
+    plan_mid4(h);
+    if (h->mid4) { h->fused = true; plan_chain(h); return; }
+    // the middle weights do not fit LDS: per-layer tiled GEMMs for the middle, still bracketed by
+    // the one-launch first layer and the one-launch gradient+update (a 16-row kernel that streamed
+    // the middle weights from L2 was 15-40 % slower than this on every such shape and was removed)
+    h->mid_generic = true;
+    h->fused = true;
+}
+
+// ---- two-launch step: tile_step_kernel plan ----------------------------------------------------
+// Every layer's weight matrix in 64 x 16 tiles, one grid; layer 0's tiles first (they also make the next
+// batch's first-layer K slabs).  Needs the row-block kernel (middle4) and at most MID4_MAX_SLABS slabs.
+void plan_chain(gnn_mlp *h) {
+    h->chain = false;
+    if (h->env_chain_off || !h->mid4) return;
+    const int L = h->L;
+    h->n_slabs = (h->ld[0] + TS_TM - 1) / TS_TM;
+    if (h->n_slabs > MID4_MAX_SLABS) return;
+    TileStepParams &t = h->tsp;
+    t = TileStepParams{};
+    t.n_layers = L - 1;
+    int tiles = 0;
+    for (int l = 0; l < L - 1; l++) {
+        GradLayer &gl = t.layer[l];
+        gl.A = h->act[l]; gl.lda = h->ld[l];
+        gl.D = h->delta[l + 1]; gl.ldd = h->ld[l + 1];
+        gl.W = h->W + h->w_off[l]; gl.V = h->V + h->w_off[l]; gl.G = h->G + h->w_off[l];
+        gl.M = h->ld[l]; gl.N = h->ld[l + 1];
+        if (h->dtype == GNN_DTYPE_BF16) { t.Ab[l] = h->actb[l]; t.Db[l] = h->deltab[l + 1]; t.Wb[l] = h->Wb + h->w_off[l]; }
+        gl.tiling = make_xcd_tiling((gl.M + TS_TM - 1) / TS_TM, gl.N / TS_TN);
+        gl.block_begin = tiles;
+        tiles += gl.tiling.blocks();
+        if (l == 0) h->ts_tiles0 = tiles;
+    }
+    h->ts_tiles = tiles;
+    const size_t n = (size_t)h->n_slabs * h->cap_rows * h->ld[1];
+    if (n >= (1ull << 30)) return; // middle4 addresses the slabs with 32-bit byte offsets
+    if (hipMalloc(reinterpret_cast<void **>(&h->slabs), sizeof(float) * n) != hipSuccess) { (void)hipGetLastError(); h->slabs = nullptr; return; }
+    if (hipMemsetAsync(h->slabs, 0, sizeof(float) * n, h->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    t.slabs = h->slabs; t.slab_rows = h->cap_rows; t.ldz = h->ld[1];
+    for (int i = 0; i < 2; i++) {
+        const size_t xn = (size_t)h->cap_rows * h->ld[0];
+        if (h->dtype == GNN_DTYPE_BF16) {
+            if (hipMalloc(reinterpret_cast<void **>(&h->xstage_b[i]), sizeof(__bf16) * xn) != hipSuccess) { (void)hipGetLastError(); h->xstage_b[i] = nullptr; return; }
+        } else {
+            if (hipMalloc(reinterpret_cast<void **>(&h->xstage[i]), sizeof(float) * xn) != hipSuccess) { (void)hipGetLastError(); h->xstage[i] = nullptr; return; }
+        }
+    }
+    h->chain = true;
+}
+
+bool slabs_hold(const gnn_mlp *h, const float *a0, const int32_t *idx, int B) {
+    return h->slab_valid && h->slab_a0 == a0 && h->slab_idx == idx && h->slab_B == B;
+}
+// the hint is good for ONE weight update
+bool take_next(gnn_mlp *h, NextBatch *nb) {
+    if (!h->have_next) return false;
+    h->have_next = false;
+    *nb = NextBatch{h->next_a0, h->next_idx, h->next_B};
+    return true;
+}
+// staged_copy: the launch that made these slabs also wrote the batch's rows to the other staging buffer
+void slabs_now_hold(gnn_mlp *h, const NextBatch &nb, bool staged_copy) {
+    h->slab_valid = true; h->slab_a0 = nb.a0; h->slab_idx = nb.idx; h->slab_B = nb.B;
+    if (staged_copy) h->xstage_cur ^= 1;
+    h->xstage_valid = staged_copy;
+}
+
+// One gradient computation on the two-launch path.  `resident`: the rows live in the dataset (a staging
+// buffer holds other data under the same address at the next call, so its slabs are never reused).
+void chain_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum, bool resident) {
+    if (!slabs_hold(h, a0, h->cur_idx, B)) {
+        const NextBatch self{a0, h->cur_idx, B};
+        launch_tile_step(h, 0, 0, &self, a0, B, 0.f, 0.f); // chain start: the slabs of this batch from the weights as they are
+        slabs_now_hold(h, self, self.idx != nullptr);
+    }
+    const bool staged = h->xstage_valid && h->cur_idx != nullptr; // the launch that made the slabs left a contiguous copy of these rows
+    h->slab_valid = false;
+    fused_forward(h, a0, y, B, true, false, false, false, true);
+    NextBatch nb{};
+    if (fused_update) {
+        const bool fwd = take_next(h, &nb);
+        launch_tile_step(h, 1, 2, fwd ? &nb : nullptr, a0, B, step_over_b, momentum, staged);
+        if (fwd) slabs_now_hold(h, nb, nb.idx != nullptr);
+        else h->xstage_valid = false;
+    } else {
+        launch_tile_step(h, 1, 1, nullptr, a0, B, 0.f, 0.f, staged);
+        if (resident) { // weights unchanged: the slabs (and the staged rows) still describe this batch
+            const bool keep = staged;
+            slabs_now_hold(h, NextBatch{a0, h->cur_idx, B});
+            h->xstage_valid = keep;
+        } else {
+            h->xstage_valid = false;
+        }
+    }
+}
+
+// Nets whose middle weights exceed LDS: per-layer GEMMs for the middle, and per CALL which of the two
+// one-launch kernels still pays. Both trade operand reuse for launch count and occupancy -- a
+// 16x16 (first layer) or 32x32 (gradient) tile re-reads its operands from L2 4-16x more often than
+// the 64/128-wide GEMM tiles -- so they win while the GEMM grids cannot fill the chip and lose once
+// they can (4096-2048-2048-1024 at 512 rows: 692 us with both, 517 us with neither).
+struct HybridChoice { bool first, grad; };
+HybridChoice hybrid_choice(const gnn_mlp *h, int B) {
+    HybridChoice c{true, true};
+    if (h->env_hybrid >= 0) { c.first = (h->env_hybrid & 1) != 0; c.grad = (h->env_hybrid & 2) != 0; return c; } // tests/development
+    const int B_pad = pad_up(B);
+    c.first = pick_tile(B_pad, h->ld[1]) == 32;
+    // ... unless the 32 x 32 wave-K GEMM has enough tiles of its own (256 x 784 x 1024: 8.3 us against 13.1 us)
+    if (c.first && !h->env_wavek_off && wavek_fits(B_pad, h->ld[1], h->ld[0]) && (B_pad / 32) * (h->ld[1] / 32) >= 192) c.first = false;
+    int64_t big = 0, all = 0; // gradient elements in layers whose GEMM grid would fill the chip on its own
+    for (int l = 0; l + 1 < h->L; l++) {
+        const int64_t e = (int64_t)h->ld[l] * h->ld[l + 1];
+        all += e;
+        if (pick_tile(h->ld[l], h->ld[l + 1]) == 128) big += e;
+    }
+    c.grad = big * 2 < all;
+    return c;
+}
+
+// Nets with at most 16 outputs, off the row-block path: last layer + output rule (+ delta_{L-2}) in one launch
+bool use_tail(const gnn_mlp *h) {
+    return !h->env_tail_off && h->dtype == GNN_DTYPE_F32 && h->out_kind == GNN_OUT_SOFTMAX_CE && h->ld[h->L - 1] == 16;
+}
+
+// bf16 twin of an A_0 row pointer: the staging rows or the resident dataset
+const __bf16 *a0_bf16(const gnn_mlp *h, const float *a0) {
+    if (a0 == h->act[0]) return h->actb[0];
+    return h->DXb + (a0 - h->DX);
+}
+
+// the three shapes every entry point is made of
+void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_prob, bool want_loss, bool want_label) {
+    if (h->dtype == GNN_DTYPE_BF16) {
+        forward_bf16(h, a0_bf16(h, a0), B);
+        run_output(h, y, B, want_prob, false, want_loss, want_label);
+        return;
+    }
+    if (h->mid4) { fused_forward(h, a0, y, B, false, want_prob, want_loss, want_label); return; }
+    const bool tail = use_tail(h);
+    if (h->mid_generic && hybrid_choice(h, B).first) {
+        launch_fwd_first(h, a0, B);
+        forward(h, a0, B, 2, tail);
+    } else {
+        forward(h, a0, B, 1, tail);
+    }
+    if (tail) launch_tail(h, a0, y, B, false, want_prob, want_loss, want_label);
+    else run_output(h, y, B, want_prob, false, want_loss, want_label);
+}
+void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum,
+                 bool resident) {
+    if (h->chain) { chain_gradient(h, a0, y, B, fused_update, step_over_b, momentum, resident); return; }
+    h->have_next = false;
+    if (h->dtype == GNN_DTYPE_BF16) {
+        const __bf16 *a0b = a0_bf16(h, a0);
+        forward_bf16(h, a0b, B);
+        run_output(h, y, B, false, true, false, false);
+        backward_bf16(h, a0b, B, fused_update, step_over_b, momentum);
+        return;
+    }
+    if (h->mid4) {
+        fused_forward(h, a0, y, B, true, false, false, false);
+        fused_gradient(h, a0, B, fused_update, step_over_b, momentum);
+        return;
+    }
+    const HybridChoice c = h->mid_generic ? hybrid_choice(h, B) : HybridChoice{false, false};
+    const bool tail = use_tail(h);
+    if (c.first) {
+        launch_fwd_first(h, a0, B);
+        forward(h, a0, B, 2, tail);
+    } else {
+        forward(h, a0, B, 1, tail);
+    }
+    if (tail) launch_tail(h, a0, y, B, true, false, false, false);
+    else run_output(h, y, B, false, true, false, false);
+    if (c.grad) {
+        backward(h, a0, B, false, 0.f, 0.f, true, tail); // delta_1..delta_{L-2} only (delta_{L-2} came from the tail kernel)
+        fused_gradient(h, a0, B, fused_update, step_over_b, momentum);
+    } else {
+        backward(h, a0, B, fused_update, step_over_b, momentum, false, tail);
+    }
+}
+
+// A handle that keeps stepping repays the ~0.4 s run-time instantiation (jit.h); never while the
+// stream is being captured into a graph (module loading is not a capturable operation).
+void maybe_specialize(gnn_mlp *h) {
+    if (h->jit_tried || h->specialization != 0 || !h->mid4) return;
+    if (++h->steps_seen < 16) return;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &st) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (st != hipStreamCaptureStatusNone) return;
+    try_specialize(h);
+}
+
+int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step, double momentum, bool resident) {
+    maybe_specialize(h);
+    ScopedTimer tm(h, GNN_K_STEP);
+    do_gradient(h, a0, y, B, true, (float)(step / (double)B), (float)momentum, resident);
+    h->time++;
+    TRY_LAUNCHES(h);
+    return GNN_OK;
+}
+
+// the next gradient computation runs on dataset rows [row0, row0 + B)
+void hint_range(gnn_mlp *h, int64_t row0, int B) {
+    h->have_next = true; h->next_a0 = h->DX + (size_t)row0 * h->ld[0]; h->next_idx = nullptr; h->next_B = B;
+}
+
+int step_on_device_indices(gnn_mlp *h, const int32_t *d_idx, int B, double step, double momentum) {
+    if (h->mid4) {
+        // fused path: its three kernels read the sampled rows of the resident dataset through the
+        // index vector themselves (two gather launches cost 14 us of a 33-us step)
+        h->cur_idx = d_idx;
+        const int rc = step_on_rows(h, h->DX, h->DY, B, step, momentum, true);
+        h->cur_idx = nullptr;
+        return rc;
+    }
+    launch_gather(h, d_idx, B);
+    if (h->dtype == GNN_DTYPE_BF16) to_bf16(h, h->act[0], h->actb[0], (size_t)pad_up(B) * h->ld[0]);
+    return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum, false);
+}
+
+} // namespace host
+} // namespace gnn

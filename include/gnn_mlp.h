@@ -36,6 +36,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what this header declares is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct gnn_mlp gnn_mlp_t;
 
@@ -275,6 +279,9 @@ typedef enum {
 int gnn_mlp_timing_enable(gnn_mlp_t *h, int on);
 int gnn_mlp_timing_read(gnn_mlp_t *h, int which, double *mean_us, int64_t *count);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

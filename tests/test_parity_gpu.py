@@ -399,7 +399,7 @@ def test_more_shapes_take_every_path(gnn, oracle_mod, dims, B, inner):
 @pytest.mark.parametrize("mask", ["0", "1", "2", "3", None])
 def test_hybrid_choices_agree_with_oracle(gnn, oracle_mod, monkeypatch, mask):
     """Nets whose middle weights exceed LDS pick per call between the one-launch first-layer /
-    gradient kernels and the per-layer GEMMs (hybrid_choice in gnn_mlp.hip); GNN_MLP_HYBRID forces
+    gradient kernels and the per-layer GEMMs (hybrid_choice in csrc/plan.hip); GNN_MLP_HYBRID forces
     each of the four combinations. All must match the oracle, fused update and gradient export."""
     import os
     if os.environ.get("GNN_MLP_PATH"):
