@@ -72,11 +72,13 @@ SYMBOLS = [
     ("gnn_mlp_dp_set_weights", C.c_int, [_H, _dp]),
     ("gnn_mlp_dp_synchronize", C.c_int, [_H]),
     ("gnn_mlp_dp_replicas_identical", C.c_int, [_H, C.POINTER(C.c_int)]),
+    ("gnn_mlp_forget_lookahead", C.c_int, [_H]),
     ("gnn_mlp_advance_time", C.c_int, [_H, C.c_int]),
     ("gnn_mlp_recover_stream", C.c_int, [_H]),
     ("gnn_mlp_specialize", C.c_int, [_H]),
     ("gnn_mlp_specialization", C.c_int, [_H]),
     ("gnn_mlp_step_launches", C.c_int, [_H]),
+    ("gnn_mlp_plan_note", C.c_char_p, [_H]),
     ("gnn_mlp_timing_enable", C.c_int, [_H, C.c_int]),
     ("gnn_mlp_timing_read", C.c_int, [_H, C.c_int, _dp, C.POINTER(C.c_int64)]),
 ]

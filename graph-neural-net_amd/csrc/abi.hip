@@ -35,6 +35,14 @@ int fail(int code, const std::string &msg) {
     return code;
 }
 const char *last_error_message() { return g_last_error.c_str(); }
+int fail_from_exception(const char *what) noexcept {
+    try {
+        g_last_error = std::string("C++ exception inside the library: ") + (what ? what : "");
+    } catch (...) { // not even the message could be stored: keep the status
+        g_last_error.clear();
+    }
+    return GNN_ERR_STATE;
+}
 
 // every launch since the last check was accepted: the runtime's sticky error and the return codes of
 // the kernels launched through function pointers / hiprtc modules (fused_forward)
@@ -121,7 +129,7 @@ extern "C" {
 const char *gnn_mlp_last_error(void) { return last_error_message(); }
 
 int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act, int last_act, int loss,
-                   int64_t seed, int dtype, int device, int max_batch, gnn_mlp_t **out) {
+                   int64_t seed, int dtype, int device, int max_batch, gnn_mlp_t **out) { return guarded([&]() -> int {
     if (!out) return fail(GNN_ERR_BAD_ARG, "out is null");
     *out = nullptr;
     if (!dims || n_dims < 2) return fail(GNN_ERR_BAD_ARG, "layerDims must hold at least 2 entries (SCE:105)");
@@ -190,8 +198,6 @@ int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act,
         for (int l = 0; l < n_dims - 1; l++) CTRY(dev_alloc(&h->actb[l], rows * h->ld[l], h->stream));
         for (int l = 1; l < n_dims; l++) CTRY(dev_alloc(&h->deltab[l], rows * h->ld[l], h->stream));
     }
-    CTRY(dev_alloc(&h->stage_x, (size_t)max_batch * dims[0], h->stream));
-    CTRY(dev_alloc(&h->stage_y, (size_t)max_batch * dims[n_dims - 1], h->stream));
     {
         size_t so = (size_t)max_batch * dims[n_dims - 1];
         if (so < (size_t)max_batch) so = (size_t)max_batch;
@@ -213,9 +219,9 @@ int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act,
     plan_fused(h);
     *out = h;
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_destroy(gnn_mlp_t *h) {
+int gnn_mlp_destroy(gnn_mlp_t *h) { return guarded([&]() -> int {
     if (!h) return GNN_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -224,7 +230,7 @@ int gnn_mlp_destroy(gnn_mlp_t *h) {
     for (float *p : h->act) fr(p);
     for (float *p : h->delta) fr(p);
     fr(h->logits); fr(h->prob); fr(h->ybuf); fr(h->lossv); fr(h->labels); fr(h->idxbuf);
-    fr(h->stage_x); fr(h->stage_y); fr(h->stage_out); fr(h->DX); fr(h->DY); fr(h->slabs);
+    fr(h->stage_out); release_host_staging(h); fr(h->DX); fr(h->DY); fr(h->slabs);
     fr(h->Wb); fr(h->DXb);
     for (int i = 0; i < 2; i++) { fr(h->xstage[i]); fr(h->xstage_b[i]); }
     for (__bf16 *p : h->actb) fr(p);
@@ -238,7 +244,7 @@ int gnn_mlp_destroy(gnn_mlp_t *h) {
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return GNN_OK;
-}
+}); }
 
 int gnn_mlp_input_dim(const gnn_mlp_t *h) { return h ? h->dims[0] : -1; }
 int gnn_mlp_output_dim(const gnn_mlp_t *h) { return h ? h->dims[h->L - 1] : -1; }
@@ -247,15 +253,15 @@ int gnn_mlp_time(const gnn_mlp_t *h) { return h ? h->time : -1; }
 int64_t gnn_mlp_dataset_size(const gnn_mlp_t *h) { return h ? h->dataset_n : -1; }
 int64_t gnn_mlp_grad_elems(const gnn_mlp_t *h) { return h ? h->n_pad : -1; }
 
-int gnn_mlp_propagate(gnn_mlp_t *h, const double *X, int B, double *out) {
+int gnn_mlp_propagate(gnn_mlp_t *h, const double *X, int B, double *out) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!X || !out) return fail(GNN_ERR_BAD_ARG, "null argument (reference: assert input != null, SCE:165)");
     TRY(check_batch(h, B));
-    TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
+    TRY(stage_batch(h, X, nullptr, B));
     do_forward(h, h->act[0], nullptr, B, true, false, false);
     TRY_LAUNCHES(h);
     return export_rows(h, h->prob, h->ld[h->L - 1], h->dims[h->L - 1], B, out);
-}
+}); }
 
 static int read_loss(gnn_mlp *h, int B, double *loss_per_sample) {
     std::vector<float> tmp((size_t)B);
@@ -270,69 +276,61 @@ static int read_labels(gnn_mlp *h, int B, int32_t *labels) {
     return GNN_OK;
 }
 
-int gnn_mlp_loss(gnn_mlp_t *h, const double *X, const double *Y, int B, double *loss_per_sample) {
+int gnn_mlp_loss(gnn_mlp_t *h, const double *X, const double *Y, int B, double *loss_per_sample) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!X || !Y || !loss_per_sample) return fail(GNN_ERR_BAD_ARG, "null argument (SCE:209)");
     TRY(check_batch(h, B));
-    const int Lm = h->L - 1;
-    TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
-    TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
+    TRY(stage_batch(h, X, Y, B));
     do_forward(h, h->act[0], h->ybuf, B, false, true, false);
     TRY_LAUNCHES(h);
     return read_loss(h, B, loss_per_sample);
-}
+}); }
 
-int gnn_mlp_argmax(gnn_mlp_t *h, const double *X, int B, int32_t *labels) {
+int gnn_mlp_argmax(gnn_mlp_t *h, const double *X, int B, int32_t *labels) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!X || !labels) return fail(GNN_ERR_BAD_ARG, "null argument");
     TRY(check_batch(h, B));
-    TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
+    TRY(stage_batch(h, X, nullptr, B));
     do_forward(h, h->act[0], nullptr, B, false, false, true);
     TRY_LAUNCHES(h);
     return read_labels(h, B, labels);
-}
+}); }
 
-int gnn_mlp_compute_gradient(gnn_mlp_t *h, const double *X, const double *Y, int B) {
+int gnn_mlp_compute_gradient(gnn_mlp_t *h, const double *X, const double *Y, int B) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!X || !Y) return fail(GNN_ERR_BAD_ARG, "null argument (SCE:231)");
     TRY(check_batch(h, B));
-    const int Lm = h->L - 1;
-    TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
-    TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
+    TRY(stage_batch(h, X, Y, B));
     do_gradient(h, h->act[0], h->ybuf, B, false, 0.f, 0.f, false);
     TRY_LAUNCHES(h);
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_weight_gradient(gnn_mlp_t *h, const double *X, const double *Y, int B, double *flat_grad) {
+int gnn_mlp_weight_gradient(gnn_mlp_t *h, const double *X, const double *Y, int B, double *flat_grad) { return guarded([&]() -> int {
     if (!flat_grad) return fail(GNN_ERR_BAD_ARG, "null output");
     TRY(gnn_mlp_compute_gradient(h, X, Y, B));
     return get_flat(h, h->G, flat_grad);
-}
+}); }
 
 int gnn_mlp_gradient_step(gnn_mlp_t *h, const double *X, const double *Y, int B, double step, double momentum,
-                          int noise) {
+                          int noise) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!X || !Y) return fail(GNN_ERR_BAD_ARG, "null argument (reference: assert batch != null, SCE:299)");
     TRY(check_batch(h, B));
     if (noise) return fail(GNN_ERR_UNSUPPORTED, "noise=true is NaN-producing in the reference (SCE:335 sqrt of a negative draw) and is not built on the GPU");
     if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
-    const int Lm = h->L - 1;
-    TRY(stage_rows(h, X, h->dims[0], h->ld[0], B, h->stage_x, h->act[0], true));
-    TRY(stage_rows(h, Y, h->dims[Lm], h->ld[Lm], B, h->stage_y, h->ybuf, false));
-    // the staging buffers are reused by the next call: pageable hipMemcpyAsync has returned
-    // only once the host data was consumed, and the convert kernels are stream-ordered.
+    TRY(stage_batch(h, X, Y, B));   // the caller's rows are not read after this returns
     h->have_next = false; // (a hint refers to dataset rows; this batch came from the host)
     return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum, false);
-}
+}); }
 
-int gnn_mlp_get_weights(gnn_mlp_t *h, double *flat) { TRY(check_handle(h)); return get_flat(h, h->W, flat); }
-int gnn_mlp_set_weights(gnn_mlp_t *h, const double *flat) { TRY(check_handle(h)); return set_flat(h, h->W, flat); }
-int gnn_mlp_get_momentum(gnn_mlp_t *h, double *flat) { TRY(check_handle(h)); return get_flat(h, h->V, flat); }
-int gnn_mlp_set_momentum(gnn_mlp_t *h, const double *flat) { TRY(check_handle(h)); return set_flat(h, h->V, flat); }
+int gnn_mlp_get_weights(gnn_mlp_t *h, double *flat) { return guarded([&]() -> int { TRY(check_handle(h)); return get_flat(h, h->W, flat); }); }
+int gnn_mlp_set_weights(gnn_mlp_t *h, const double *flat) { return guarded([&]() -> int { TRY(check_handle(h)); return set_flat(h, h->W, flat); }); }
+int gnn_mlp_get_momentum(gnn_mlp_t *h, double *flat) { return guarded([&]() -> int { TRY(check_handle(h)); return get_flat(h, h->V, flat); }); }
+int gnn_mlp_set_momentum(gnn_mlp_t *h, const double *flat) { return guarded([&]() -> int { TRY(check_handle(h)); return set_flat(h, h->V, flat); }); }
 
 // ---- dataset ------------------------------------------------------------------------------
-static int alloc_dataset(gnn_mlp *h, int64_t N) {
+static int alloc_dataset(gnn_mlp *h, int64_t N) { return guarded([&]() -> int {
     HIP_TRY(hipStreamSynchronize(h->stream)); // nothing in flight may still read the old dataset
     if (h->DX) { (void)hipFree(h->DX); h->DX = nullptr; }
     if (h->DY) { (void)hipFree(h->DY); h->DY = nullptr; }
@@ -344,9 +342,9 @@ static int alloc_dataset(gnn_mlp *h, int64_t N) {
     TRY(dev_alloc(&h->DY, rows * h->ld[h->L - 1], h->stream));
     if (h->dtype == GNN_DTYPE_BF16) TRY(dev_alloc(&h->DXb, rows * h->ld[0], h->stream));
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_upload_dataset(gnn_mlp_t *h, const double *X, const double *Y, int64_t N) {
+int gnn_mlp_upload_dataset(gnn_mlp_t *h, const double *X, const double *Y, int64_t N) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!X || !Y || N <= 0) return fail(GNN_ERR_BAD_ARG, "bad dataset");
     TRY(alloc_dataset(h, N));
@@ -372,9 +370,9 @@ int gnn_mlp_upload_dataset(gnn_mlp_t *h, const double *X, const double *Y, int64
     TRY_LAUNCHES(h);
     h->dataset_n = N;
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_upload_dataset_u8(gnn_mlp_t *h, const uint8_t *pixels, const uint8_t *labels, int64_t N) {
+int gnn_mlp_upload_dataset_u8(gnn_mlp_t *h, const uint8_t *pixels, const uint8_t *labels, int64_t N) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!pixels || !labels || N <= 0) return fail(GNN_ERR_BAD_ARG, "bad dataset");
     TRY(alloc_dataset(h, N));
@@ -392,19 +390,19 @@ int gnn_mlp_upload_dataset_u8(gnn_mlp_t *h, const uint8_t *pixels, const uint8_t
     TRY_LAUNCHES(h);
     h->dataset_n = N;
     return GNN_OK;
-}
+}); }
 
 
-int gnn_mlp_gradient_step_range(gnn_mlp_t *h, int64_t first, int B, double step, double momentum, int noise) {
+int gnn_mlp_gradient_step_range(gnn_mlp_t *h, int64_t first, int B, double step, double momentum, int noise) { return guarded([&]() -> int {
     TRY(check_handle(h));
     TRY(check_step_args(h, B, step, noise));
     TRY(check_range(h, first, B));
     return step_on_rows(h, h->DX + (size_t)first * h->ld[0], h->DY + (size_t)first * h->ld[h->L - 1], B, step,
                         momentum, true);
-}
+}); }
 
 
-int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double step, double momentum) {
+int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double step, double momentum) { return guarded([&]() -> int {
     TRY(check_handle(h));
     TRY(check_step_args(h, B, step, 0));
     if (!h->DX) return fail(GNN_ERR_STATE, "no dataset uploaded");
@@ -482,10 +480,10 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
                          momentum, true));
     }
     return GNN_OK;
-}
+}); }
 
 
-int gnn_mlp_gradient_step_indexed(gnn_mlp_t *h, const int32_t *idx, int B, double step, double momentum, int noise) {
+int gnn_mlp_gradient_step_indexed(gnn_mlp_t *h, const int32_t *idx, int B, double step, double momentum, int noise) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!idx) return fail(GNN_ERR_BAD_ARG, "null index list");
     TRY(check_step_args(h, B, step, noise));
@@ -495,9 +493,9 @@ int gnn_mlp_gradient_step_indexed(gnn_mlp_t *h, const int32_t *idx, int B, doubl
     HIP_TRY(hipMemcpyAsync(h->idxbuf, idx, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, h->stream));
     h->slab_valid = false; h->have_next = false; // idxbuf is reused: its address does not identify a batch
     return step_on_device_indices(h, h->idxbuf, B, step, momentum);
-}
+}); }
 
-int gnn_mlp_loss_range(gnn_mlp_t *h, int64_t first, int B, double *loss_per_sample) {
+int gnn_mlp_loss_range(gnn_mlp_t *h, int64_t first, int B, double *loss_per_sample) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!loss_per_sample) return fail(GNN_ERR_BAD_ARG, "null output");
     TRY(check_batch(h, B));
@@ -505,9 +503,9 @@ int gnn_mlp_loss_range(gnn_mlp_t *h, int64_t first, int B, double *loss_per_samp
     do_forward(h, h->DX + (size_t)first * h->ld[0], h->DY + (size_t)first * h->ld[h->L - 1], B, false, true, false);
     TRY_LAUNCHES(h);
     return read_loss(h, B, loss_per_sample);
-}
+}); }
 
-int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels) {
+int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!labels) return fail(GNN_ERR_BAD_ARG, "null output");
     TRY(check_batch(h, B));
@@ -515,25 +513,25 @@ int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels) {
     do_forward(h, h->DX + (size_t)first * h->ld[0], nullptr, B, false, false, true);
     TRY_LAUNCHES(h);
     return read_labels(h, B, labels);
-}
+}); }
 
 // ---- data-parallel hooks --------------------------------------------------------------------
-int gnn_mlp_grad_device_ptr(gnn_mlp_t *h, void **dev_ptr) {
+int gnn_mlp_grad_device_ptr(gnn_mlp_t *h, void **dev_ptr) { return guarded([&]() -> int {
     if (!h || !dev_ptr) return fail(GNN_ERR_BAD_ARG, "null argument");
     *dev_ptr = h->G;
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_bind_grad_buffer(gnn_mlp_t *h, void *dev_ptr, int64_t n_elems) {
+int gnn_mlp_bind_grad_buffer(gnn_mlp_t *h, void *dev_ptr, int64_t n_elems) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!dev_ptr) { h->G = h->G_own; return GNN_OK; }
     if (n_elems < h->n_pad) return fail(GNN_ERR_BAD_ARG, "gradient buffer shorter than gnn_mlp_grad_elems()");
     if (reinterpret_cast<uintptr_t>(dev_ptr) % 16) return fail(GNN_ERR_BAD_ARG, "gradient buffer must be 16-byte aligned");
     h->G = static_cast<float *>(dev_ptr);
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_set_stream(gnn_mlp_t *h, void *hip_stream) {
+int gnn_mlp_set_stream(gnn_mlp_t *h, void *hip_stream) { return guarded([&]() -> int {
     TRY(check_handle(h));
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
@@ -541,9 +539,9 @@ int gnn_mlp_set_stream(gnn_mlp_t *h, void *hip_stream) {
     else (void)hipGetLastError();
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_compute_gradient_range(gnn_mlp_t *h, int64_t first, int B) {
+int gnn_mlp_compute_gradient_range(gnn_mlp_t *h, int64_t first, int B) { return guarded([&]() -> int {
     TRY(check_handle(h));
     TRY(check_batch(h, B));
     TRY(check_range(h, first, B));
@@ -552,17 +550,17 @@ int gnn_mlp_compute_gradient_range(gnn_mlp_t *h, int64_t first, int B) {
     do_gradient(h, a0, h->DY + (size_t)first * h->ld[h->L - 1], B, false, 0.f, 0.f, true);
     TRY_LAUNCHES(h);
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_hint_next_range(gnn_mlp_t *h, int64_t first, int B) {
+int gnn_mlp_hint_next_range(gnn_mlp_t *h, int64_t first, int B) { return guarded([&]() -> int {
     TRY(check_handle(h));
     TRY(check_batch(h, B));
     TRY(check_range(h, first, B));
     hint_range(h, first, B);
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentum) {
+int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentum) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (B_global <= 0) return fail(GNN_ERR_BAD_ARG, "B_global must be positive");
     if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
@@ -578,15 +576,21 @@ int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentu
     h->time++;
     TRY_LAUNCHES(h);
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_advance_time(gnn_mlp_t *h, int steps) {
-    if (!h || h->time + steps < 0) return fail(GNN_ERR_BAD_ARG, "bad argument");
-    h->time += steps; // negative: steps that were only CAPTURED (enqueued into a graph, not run)
+int gnn_mlp_forget_lookahead(gnn_mlp_t *h) {
+    if (!h) return fail(GNN_ERR_BAD_ARG, "null handle");
+    h->slab_valid = false; h->have_next = false; h->xstage_valid = false;
     return GNN_OK;
 }
 
-int gnn_mlp_recover_stream(gnn_mlp_t *h) {
+int gnn_mlp_advance_time(gnn_mlp_t *h, int steps) { return guarded([&]() -> int {
+    if (!h || h->time + steps < 0) return fail(GNN_ERR_BAD_ARG, "bad argument");
+    h->time += steps; // negative: steps that were only CAPTURED (enqueued into a graph, not run)
+    return GNN_OK;
+}); }
+
+int gnn_mlp_recover_stream(gnn_mlp_t *h) { return guarded([&]() -> int {
     TRY(check_handle(h));
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(h->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
@@ -600,34 +604,35 @@ int gnn_mlp_recover_stream(gnn_mlp_t *h) {
     }
     for (int i = 0; i < 8 && hipGetLastError() != hipSuccess; i++) {}
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_synchronize(gnn_mlp_t *h) {
+int gnn_mlp_synchronize(gnn_mlp_t *h) { return guarded([&]() -> int {
     TRY(check_handle(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return GNN_OK;
-}
+}); }
 
 // ---- shape specialisation ---------------------------------------------------------------------
-int gnn_mlp_specialize(gnn_mlp_t *h) {
+int gnn_mlp_specialize(gnn_mlp_t *h) { return guarded([&]() -> int {
     TRY(check_handle(h));
     h->jit_tried = false;
     try_specialize(h);
     return GNN_OK;
-}
+}); }
 int gnn_mlp_specialization(const gnn_mlp_t *h) { return h ? h->specialization : -1; }
 int gnn_mlp_step_launches(const gnn_mlp_t *h) { return !h ? -1 : h->chain ? 2 : h->mid4 ? 3 : 0; }
+const char *gnn_mlp_plan_note(const gnn_mlp_t *h) { return h ? h->plan_note.c_str() : ""; }
 
 // ---- measurement ---------------------------------------------------------------------------
-int gnn_mlp_timing_enable(gnn_mlp_t *h, int on) {
+int gnn_mlp_timing_enable(gnn_mlp_t *h, int on) { return guarded([&]() -> int {
     TRY(check_handle(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->timing = on != 0;
     for (TimerClass &t : h->timers) t.used = 0;
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_timing_read(gnn_mlp_t *h, int which, double *mean_us, int64_t *count) {
+int gnn_mlp_timing_read(gnn_mlp_t *h, int which, double *mean_us, int64_t *count) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (which < 0 || which > 4 || !mean_us || !count) return fail(GNN_ERR_BAD_ARG, "bad timing query");
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -641,6 +646,6 @@ int gnn_mlp_timing_read(gnn_mlp_t *h, int which, double *mean_us, int64_t *count
     *count = (int64_t)t.used;
     *mean_us = t.used ? total * 1000.0 / (double)t.used : 0.0;
     return GNN_OK;
-}
+}); }
 
 } // extern "C"

@@ -27,7 +27,7 @@ const char kCkptMagic[8] = {'G', 'N', 'N', 'M', 'L', 'P', '2', 0};
 
 extern "C" {
 
-int gnn_mlp_save_checkpoint(gnn_mlp_t *h, const char *path) {
+int gnn_mlp_save_checkpoint(gnn_mlp_t *h, const char *path) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!path) return fail(GNN_ERR_BAD_ARG, "null path");
     std::vector<double> w((size_t)h->n_params), v((size_t)h->n_params);
@@ -47,9 +47,9 @@ int gnn_mlp_save_checkpoint(gnn_mlp_t *h, const char *path) {
     ok = ok && fwrite(&sum, 8, 1, f) == 1;
     ok = (fclose(f) == 0) && ok;
     return ok ? GNN_OK : fail(GNN_ERR_BAD_ARG, std::string("short write to ") + path);
-}
+}); }
 
-int gnn_mlp_load_checkpoint(gnn_mlp_t *h, const char *path) {
+int gnn_mlp_load_checkpoint(gnn_mlp_t *h, const char *path) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!path) return fail(GNN_ERR_BAD_ARG, "null path");
     FILE *f = fopen(path, "rb");
@@ -90,6 +90,6 @@ int gnn_mlp_load_checkpoint(gnn_mlp_t *h, const char *path) {
     TRY(set_flat(h, h->V, v.data()));
     h->time = cfg[5];
     return GNN_OK;
-}
+}); }
 
 } // extern "C"

@@ -15,28 +15,45 @@ namespace {
 // RCCL is bound at run time: libgnn_mlp_hip.so itself has no link dependency on it
 struct RcclApi {
     void *lib = nullptr;
+    bool ok = false; // every entry point below resolved (a library that lacks one is closed again and never used)
     int (*CommInitAll)(void **, int, const int *) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::mutex mu;
     bool load(std::string *why) {
         std::lock_guard<std::mutex> lock(mu);
-        if (lib) return true;
+        if (ok) return true;
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;
         }
-        if (!lib) { *why = std::string("RCCL not found: ") + dlerror(); return false; }
+        if (!lib) {
+            const char *e = dlerror();
+            *why = std::string("RCCL not found: ") + (e ? e : "dlopen failed");
+            return false;
+        }
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+        ReduceScatter = reinterpret_cast<decltype(ReduceScatter)>(dlsym(lib, "ncclReduceScatter"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd) { *why = "RCCL lacks the expected entry points"; return false; }
+        if (!CommInitAll || !CommDestroy || !AllReduce || !ReduceScatter || !AllGather || !GroupStart || !GroupEnd) {
+            *why = "RCCL lacks the expected entry points";
+            (void)dlclose(lib);
+            lib = nullptr;
+            CommInitAll = nullptr; CommDestroy = nullptr; AllReduce = nullptr; ReduceScatter = nullptr; AllGather = nullptr;
+            GroupStart = nullptr; GroupEnd = nullptr; GetErrorString = nullptr;
+            return false;
+        }
+        ok = true;
         return true;
     }
 };
@@ -134,7 +151,7 @@ int dp_check(const gnn_mlp_dp *d) { return d ? GNN_OK : fail(GNN_ERR_BAD_ARG, "n
 extern "C" {
 
 int gnn_mlp_dp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act, int last_act, int loss, int64_t seed,
-                      int dtype, const int32_t *devices, int n_dev, int max_batch, int reducer, gnn_mlp_dp_t **out) {
+                      int dtype, const int32_t *devices, int n_dev, int max_batch, int reducer, gnn_mlp_dp_t **out) { return guarded([&]() -> int {
     if (!out) return fail(GNN_ERR_BAD_ARG, "out is null");
     *out = nullptr;
     if (!devices || n_dev < 1 || n_dev > DP_MAX_REPLICAS) return fail(GNN_ERR_BAD_ARG, "n_dev must be 1..16");
@@ -190,9 +207,9 @@ int gnn_mlp_dp_create(const int32_t *dims, int n_dims, int out_kind, int inner_a
     }
     *out = d;
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_dp_destroy(gnn_mlp_dp_t *d) {
+int gnn_mlp_dp_destroy(gnn_mlp_dp_t *d) { return guarded([&]() -> int {
     if (!d) return GNN_OK;
     for (size_t r = 0; r < d->rep.size(); r++) {
         (void)hipSetDevice(d->dev[r]);
@@ -211,18 +228,18 @@ int gnn_mlp_dp_destroy(gnn_mlp_dp_t *d) {
     for (gnn_mlp *h : d->rep) (void)gnn_mlp_destroy(h);
     delete d;
     return GNN_OK;
-}
+}); }
 
 int gnn_mlp_dp_num_replicas(const gnn_mlp_dp_t *d) { return d ? d->n : -1; }
 
-int gnn_mlp_dp_replica(gnn_mlp_dp_t *d, int r, gnn_mlp_t **out) {
+int gnn_mlp_dp_replica(gnn_mlp_dp_t *d, int r, gnn_mlp_t **out) { return guarded([&]() -> int {
     TRY(dp_check(d));
     if (!out || r < 0 || r >= d->n) return fail(GNN_ERR_BAD_ARG, "replica index out of range");
     *out = d->rep[r];
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_dp_gradient_step(gnn_mlp_dp_t *d, const double *X, const double *Y, int B, double step, double momentum, int noise) {
+int gnn_mlp_dp_gradient_step(gnn_mlp_dp_t *d, const double *X, const double *Y, int B, double step, double momentum, int noise) { return guarded([&]() -> int {
     TRY(dp_check(d));
     if (!X || !Y) return fail(GNN_ERR_BAD_ARG, "null argument (reference: assert batch != null, SCE:299)");
     if (B <= 0) return fail(GNN_ERR_BAD_ARG, "batch must be non-empty (SCE:300)");
@@ -242,13 +259,13 @@ int gnn_mlp_dp_gradient_step(gnn_mlp_dp_t *d, const double *X, const double *Y, 
     TRY(dp_reduce_and_update(d, B, step, momentum));
     d->steps++;
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_dp_upload_dataset(gnn_mlp_dp_t *d, const double *X, const double *Y, int64_t N) {
+int gnn_mlp_dp_upload_dataset(gnn_mlp_dp_t *d, const double *X, const double *Y, int64_t N) { return guarded([&]() -> int {
     TRY(dp_check(d));
     for (int r = 0; r < d->n; r++) TRY(gnn_mlp_upload_dataset(d->rep[r], X, Y, N)); // every replica holds every row: any batch can be sharded
     return GNN_OK;
-}
+}); }
 
 static int dp_step_range(gnn_mlp_dp *d, int64_t first, int B, double step, double momentum, int64_t next_first) {
     for (int r = 0; r < d->n; r++) {
@@ -266,16 +283,16 @@ static int dp_step_range(gnn_mlp_dp *d, int64_t first, int B, double step, doubl
     return GNN_OK;
 }
 
-int gnn_mlp_dp_gradient_step_range(gnn_mlp_dp_t *d, int64_t first, int B, double step, double momentum, int noise) {
+int gnn_mlp_dp_gradient_step_range(gnn_mlp_dp_t *d, int64_t first, int B, double step, double momentum, int noise) { return guarded([&]() -> int {
     TRY(dp_check(d));
     if (B <= 0 || B > d->max_batch) return fail(GNN_ERR_BAD_ARG, "B out of range");
     if (noise) return fail(GNN_ERR_UNSUPPORTED, "noise=true is not built on the GPU (SCE:335)");
     if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
     if (first < 0 || first + B > d->rep[0]->dataset_n) return fail(GNN_ERR_BAD_ARG, "dataset rows out of range");
     return dp_step_range(d, first, B, step, momentum, -1);
-}
+}); }
 
-int gnn_mlp_dp_train_range(gnn_mlp_dp_t *d, int64_t first, int B, int n_steps, double step, double momentum) {
+int gnn_mlp_dp_train_range(gnn_mlp_dp_t *d, int64_t first, int B, int n_steps, double step, double momentum) { return guarded([&]() -> int {
     TRY(dp_check(d));
     if (B <= 0 || B > d->max_batch) return fail(GNN_ERR_BAD_ARG, "B out of range");
     if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
@@ -288,21 +305,21 @@ int gnn_mlp_dp_train_range(gnn_mlp_dp_t *d, int64_t first, int B, int n_steps, d
         TRY(dp_step_range(d, row0, B, step, momentum, nxt));
     }
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_dp_set_weights(gnn_mlp_dp_t *d, const double *flat) {
+int gnn_mlp_dp_set_weights(gnn_mlp_dp_t *d, const double *flat) { return guarded([&]() -> int {
     TRY(dp_check(d));
     for (int r = 0; r < d->n; r++) TRY(gnn_mlp_set_weights(d->rep[r], flat));
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_dp_synchronize(gnn_mlp_dp_t *d) {
+int gnn_mlp_dp_synchronize(gnn_mlp_dp_t *d) { return guarded([&]() -> int {
     TRY(dp_check(d));
     for (int r = 0; r < d->n; r++) TRY(gnn_mlp_synchronize(d->rep[r]));
     return GNN_OK;
-}
+}); }
 
-int gnn_mlp_dp_replicas_identical(gnn_mlp_dp_t *d, int *identical) {
+int gnn_mlp_dp_replicas_identical(gnn_mlp_dp_t *d, int *identical) { return guarded([&]() -> int {
     TRY(dp_check(d));
     if (!identical) return fail(GNN_ERR_BAD_ARG, "null output");
     std::vector<double> w0((size_t)d->rep[0]->n_params), v0(w0.size()), w(w0.size()), v(w0.size());
@@ -316,6 +333,6 @@ int gnn_mlp_dp_replicas_identical(gnn_mlp_dp_t *d, int *identical) {
             d->rep[r]->time != d->rep[0]->time) *identical = 0;
     }
     return GNN_OK;
-}
+}); }
 
 } // extern "C"

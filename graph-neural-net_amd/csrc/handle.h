@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -38,7 +40,15 @@ struct gnn_mlp {
     std::vector<float *> delta; // delta[l] = dE/dz_l, l = 1..L-1
     float *logits = nullptr, *prob = nullptr, *ybuf = nullptr, *lossv = nullptr;
     int32_t *labels = nullptr, *idxbuf = nullptr;
-    double *stage_x = nullptr, *stage_y = nullptr, *stage_out = nullptr;
+    double *stage_out = nullptr;
+    // host batches (gnn_mlp_propagate / _loss / _gradient_step ...): pinned f32 slots the calling thread converts the
+    // caller's fp64 rows into and the staging kernel reads across PCIe; a slot is rewritten only after the kernel that
+    // read it has finished (its event), so call s+1's conversion overlaps step s's kernels (launch_misc.hip)
+    static constexpr int kHostSlots = 3;
+    float *pin[kHostSlots] = {nullptr, nullptr, nullptr};
+    hipEvent_t pin_done[kHostSlots] = {nullptr, nullptr, nullptr};
+    bool pin_busy[kHostSlots] = {false, false, false};
+    int pin_next = 0;
 
     float *DX = nullptr, *DY = nullptr; // device-resident dataset (A_0 = f(x) and y)
     // GNN_DTYPE_BF16 (gemm_bf16.h): bf16 roundings of every GEMM operand, written once by its producer
@@ -69,6 +79,7 @@ struct gnn_mlp {
     int ts_tiles = 0, ts_tiles0 = 0; // blocks of all layers / of layer 0 alone
     float *slabs = nullptr;
     int n_slabs = 0;
+    std::string plan_note;    // why the net is NOT on the two-launch path (empty when it is): gnn_mlp_plan_note
     // the batch whose first-layer sums (for the CURRENT weights) the slabs hold
     bool slab_valid = false; const float *slab_a0 = nullptr; const int32_t *slab_idx = nullptr; int slab_B = 0;
     // the batch the next gradient computation will run on (gnn_mlp_hint_next_range, train loops); consumed by the
@@ -135,6 +146,22 @@ int set_flat(gnn_mlp *h, float *dev, const double *flat);
         int rc_ = (expr);              \
         if (rc_ != GNN_OK) return rc_; \
     } while (0)
+
+// Every entry point of the C ABI runs its body through this: the header promises that nothing throws or aborts
+// across the boundary (a JVM caller would be taken down by std::terminate), and the bodies use std::vector,
+// std::string, std::thread and new.  An exception becomes a status + message like any other failure.
+int fail_from_exception(const char *what) noexcept;
+template <class F> int guarded(F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail_from_exception("out of host memory");
+    } catch (const std::exception &e) {
+        return fail_from_exception(e.what());
+    } catch (...) {
+        return fail_from_exception("unknown C++ exception");
+    }
+}
 
 inline int grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
@@ -233,7 +260,8 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
 void launch_convert_rows(gnn_mlp *h, const double *src, int d, float *dst, int ld, int64_t rows, int64_t rows_pad, int act, int apply_act);
 void launch_encode_u8(gnn_mlp *h, const uint8_t *pix, int d, float *dst, int ld, int64_t rows, int act);
 void launch_onehot_u8(gnn_mlp *h, const uint8_t *lab, int n_classes, float *dst, int ld, int64_t rows);
-int stage_rows(gnn_mlp *h, const double *src, int d, int ld, int B, double *stage, float *dst, bool apply_act);
+int stage_batch(gnn_mlp *h, const double *X, const double *Y, int B); // host fp64 rows -> act[0] = f(x), ybuf (Y may be null)
+void release_host_staging(gnn_mlp *h);
 int export_rows(gnn_mlp *h, const float *src, int ld, int d, int B, double *host_dst);
 void launch_gather(gnn_mlp *h, const int32_t *d_idx, int B);
 void launch_flat_update(gnn_mlp *h, int B_global, double step, double momentum);

@@ -590,6 +590,37 @@ static __global__ __launch_bounds__(256) void convert_rows_f64_kernel(const doub
     }
 }
 
+// A host batch as the boundary hands it over (NN:16-51 take double[] rows): the library has already rounded the rows
+// to f32 into a PINNED host buffer (the same RNE conversion as above, done by the calling thread while it copies), and
+// this kernel pulls them across PCIe itself -- no copy-engine command, no staging buffer in HBM: X [rows][d0] then
+// Y [rows][dl], unpadded.  Writes A_0 = f(x) (SCE:183-186) and the expected rows in the padded layout, zeros elsewhere.
+struct StageBatchParams {
+    const float *src_x; const float *src_y; // pinned host memory (device-visible); src_y may be null
+    int d0, dl;
+    float *dst_x; int ld0;
+    float *dst_y; int ldl;
+    int64_t rows, rows_pad;
+    int act;
+    __bf16 *dst_xb;                         // bf16 mode: the rounding of A_0, same ld (may be null)
+};
+static __global__ __launch_bounds__(256) void stage_batch_kernel(StageBatchParams p) {
+    const int64_t nx = p.rows_pad * p.ld0, total = nx + (p.src_y ? p.rows_pad * p.ldl : 0);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (i < nx) {
+            const int64_t r = i / p.ld0;
+            const int c = (int)(i - r * p.ld0);
+            float v = 0.f;
+            if (r < p.rows && c < p.d0) v = act_fn(p.act, p.src_x[r * p.d0 + c]);
+            p.dst_x[i] = v;
+            if (p.dst_xb) p.dst_xb[i] = (__bf16)v;
+        } else {
+            const int64_t j = i - nx, r = j / p.ldl;
+            const int c = (int)(j - r * p.ldl);
+            p.dst_y[j] = (r < p.rows && c < p.dl) ? p.src_y[r * p.dl + c] : 0.f;
+        }
+    }
+}
+
 // raw IDX bytes -> A_0 = f(pixel/255.0) (MT:98) and one-hot labels (MT:112-118)
 static __global__ __launch_bounds__(256) void encode_u8_kernel(const uint8_t *__restrict__ pix, int d,
                                                        float *__restrict__ dst, int ld, int64_t rows,

@@ -18,13 +18,60 @@ void launch_onehot_u8(gnn_mlp *h, const uint8_t *lab, int n_classes, float *dst,
     hipLaunchKernelGGL(onehot_u8_kernel, dim3(grid_for(rows * ld)), dim3(256), 0, h->stream, lab, n_classes, dst, ld, rows, rows);
 }
 
-// host fp64 rows -> device staging -> padded f32 (A_0 = f(x) when apply_act)
-int stage_rows(gnn_mlp *h, const double *src, int d, int ld, int B, double *stage, float *dst, bool apply_act) {
-    HIP_TRY(hipMemcpyAsync(stage, src, sizeof(double) * (size_t)B * d, hipMemcpyHostToDevice, h->stream));
-    const int64_t rows_pad = pad_up(B);
-    launch_convert_rows(h, stage, d, dst, ld, (int64_t)B, rows_pad, h->inner_act, apply_act ? 1 : 0);
-    if (h->dtype == GNN_DTYPE_BF16 && dst == h->act[0]) to_bf16(h, dst, h->actb[0], (size_t)rows_pad * ld);
+// ---- host batches --------------------------------------------------------------------------------------------
+// The reference's call shape is gradientStep(double[] rows) once per iteration (NNT:83): 0.81 MB of fp64 per call at
+// 784-300-100-10 / B = 128.  A pageable hipMemcpyAsync of that is a synchronous copy into the runtime's own staging
+// memory plus a DMA plus a convert kernel (66-97 us per step in round 2).  Here the calling thread rounds the rows to
+// f32 straight into a pinned slot (half the bytes written and half the bytes crossing PCIe; the same RNE rounding the
+// GPU's cvt applies), the staging kernel reads the slot across PCIe, and the call returns: the NEXT call's conversion
+// runs while this step's kernels do.  No host pointer outlives the call.
+namespace {
+void rows_to_f32(const double *src, float *dst, size_t n) {
+    for (size_t i = 0; i < n; i++) dst[i] = (float)src[i];
+}
+__attribute__((target("avx2"))) void rows_to_f32_avx2(const double *src, float *dst, size_t n) {
+    for (size_t i = 0; i < n; i++) dst[i] = (float)src[i]; // (vectorised by the compiler: vcvtpd2ps)
+}
+} // namespace
+
+int stage_batch(gnn_mlp *h, const double *X, const double *Y, int B) {
+    const int d0 = h->dims[0], dl = h->dims[h->L - 1], Lm = h->L - 1;
+    const size_t cap = (size_t)h->max_batch * (size_t)(d0 + dl);
+    const int slot = h->pin_next;
+    if (!h->pin[slot]) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->pin[slot]), sizeof(float) * cap, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&h->pin_done[slot], hipEventDisableTiming));
+    }
+    if (h->pin_busy[slot]) { // the staging kernel of kHostSlots calls ago: long finished unless the caller outruns the GPU
+        HIP_TRY(hipEventSynchronize(h->pin_done[slot]));
+        h->pin_busy[slot] = false;
+    }
+    float *px = h->pin[slot], *py = px + (size_t)B * d0;
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { rows_to_f32_avx2(X, px, (size_t)B * d0); if (Y) rows_to_f32_avx2(Y, py, (size_t)B * dl); }
+    else { rows_to_f32(X, px, (size_t)B * d0); if (Y) rows_to_f32(Y, py, (size_t)B * dl); }
+    StageBatchParams p{};
+    p.src_x = px; p.src_y = Y ? py : nullptr;
+    p.d0 = d0; p.dl = dl;
+    p.dst_x = h->act[0]; p.ld0 = h->ld[0];
+    p.dst_y = h->ybuf; p.ldl = h->ld[Lm];
+    p.rows = B; p.rows_pad = pad_up(B);
+    p.act = h->inner_act;
+    p.dst_xb = (h->dtype == GNN_DTYPE_BF16) ? h->actb[0] : nullptr;
+    const int64_t total = p.rows_pad * ((int64_t)p.ld0 + (Y ? p.ldl : 0));
+    hipLaunchKernelGGL(stage_batch_kernel, dim3(grid_for(total)), dim3(256), 0, h->stream, p);
+    HIP_TRY(hipEventRecord(h->pin_done[slot], h->stream));
+    h->pin_busy[slot] = true;
+    h->pin_next = (slot + 1) % gnn_mlp::kHostSlots;
     return GNN_OK;
+}
+
+void release_host_staging(gnn_mlp *h) {
+    for (int i = 0; i < gnn_mlp::kHostSlots; i++) {
+        if (h->pin_done[i]) { (void)hipEventDestroy(h->pin_done[i]); h->pin_done[i] = nullptr; }
+        if (h->pin[i]) { (void)hipHostFree(h->pin[i]); h->pin[i] = nullptr; }
+        h->pin_busy[i] = false;
+    }
 }
 
 int export_rows(gnn_mlp *h, const float *src, int ld, int d, int B, double *host_dst) {

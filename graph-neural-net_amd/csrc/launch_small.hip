@@ -62,13 +62,13 @@ const void *mid4_function(const gnn_mlp *h, int variant) {
 
 void plan_mid4(gnn_mlp *h) {
     h->mid4 = false;
-    if (h->env_path == 2) return; // tests: force the per-layer middle
+    if (h->env_path == 2) { h->plan_note = "row-block kernel switched off (GNN_MLP_PATH=nomid4)"; return; } // tests: force the per-layer middle
     const int L = h->L, Lm = L - 1;
     Mid4Params &m = h->mid4p;
     m = Mid4Params{};
     const bool bf16 = h->dtype == GNN_DTYPE_BF16;
     m.plan = make_mid4_plan(h->dims.data(), L, bf16);
-    if (!m.plan.ok) return;
+    if (!m.plan.ok) return; // (plan_fused notes that the middle weights do not fit LDS)
     h->mid4_lds_bytes = (size_t)m.plan.lds_floats * sizeof(float);
     for (int l = 1; l < Lm; l++) { m.W[l] = h->W + h->w_off[l]; m.act[l] = h->act[l]; }
     for (int l = 1; l <= Lm; l++) m.delta[l] = h->delta[l];

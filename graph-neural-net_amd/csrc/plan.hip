@@ -17,9 +17,10 @@ void plan_fused(gnn_mlp *h) {
     h->fused = false;
     h->mid4 = false;
     h->mid_generic = false;
-    if (h->env_path == 1) return;
+    h->plan_note.clear();
+    if (h->env_path == 1) { h->plan_note = "per-layer GEMMs forced (GNN_MLP_PATH=generic)"; return; }
     const int L = h->L, Lm = L - 1;
-    if (L < 3 || L > MAX_LAYERS) return;
+    if (L < 3 || L > MAX_LAYERS) { h->plan_note = "fewer than 3 or more than 8 layers: per-layer GEMMs"; return; }
     if (h->dtype != GNN_DTYPE_F32) {
         // bf16 operands: per-layer GEMMs (gemm_bf16.h) for inference and for nets off the row-block path; training
         // of a net that fits the row-block kernel takes the two-launch path in bf16 (tile_step_bf16_kernel + the bf16
@@ -27,6 +28,7 @@ void plan_fused(gnn_mlp *h) {
         plan_mid4(h);
         if (h->mid4) plan_chain(h);
         if (!h->chain) h->mid4 = false;
+        if (!h->chain && h->plan_note.empty()) h->plan_note = "bf16: the row-block kernel exists for the two-launch path only; per-layer bf16 GEMMs";
         return;
     }
     // gradient tiles: every layer's 32x32 tiles in one grid (shared by both middle kernels)
@@ -65,6 +67,7 @@ void plan_fused(gnn_mlp *h) {
     // the middle weights from L2 was 15-40 % slower than this on every such shape and was removed)
     h->mid_generic = true;
     h->fused = true;
+    if (h->plan_note.empty()) h->plan_note = "the middle weights do not fit one workgroup's LDS: per-layer GEMMs between the one-launch first layer and gradient";
 }
 
 // ---- two-launch step: tile_step_kernel plan ----------------------------------------------------
@@ -72,12 +75,37 @@ void plan_fused(gnn_mlp *h) {
 // batch's first-layer K slabs).  Needs the row-block kernel (middle4) and at most MID4_MAX_SLABS slabs.
 void plan_chain(gnn_mlp *h) {
     h->chain = false;
-    if (h->env_chain_off || !h->mid4) return;
+    h->n_slabs = 0;
+    h->tsp = TileStepParams{};
+    if (h->env_chain_off) { h->plan_note = "two-launch path switched off (GNN_MLP_CHAIN=0)"; return; }
+    if (!h->mid4) return; // (plan_mid4 said why)
     const int L = h->L;
-    h->n_slabs = (h->ld[0] + TS_TM - 1) / TS_TM;
-    if (h->n_slabs > MID4_MAX_SLABS) return;
+    const int n_slabs = (h->ld[0] + TS_TM - 1) / TS_TM;
+    if (n_slabs > MID4_MAX_SLABS) { h->plan_note = "more than 16 first-layer K slabs (input width above 1024): three launches per step"; return; }
+    const size_t n = (size_t)n_slabs * h->cap_rows * h->ld[1];
+    if (n >= (1ull << 30)) { h->plan_note = "slab buffer beyond 2^30 floats (the row-block kernel addresses it with 32-bit byte offsets)"; return; }
+    // every allocation of the path, or none: a failure leaves the handle on the three-launch / per-layer path with nothing held
+    auto give_up = [&](const char *what) {
+        (void)hipGetLastError();
+        if (h->slabs) { (void)hipFree(h->slabs); h->slabs = nullptr; }
+        for (int i = 0; i < 2; i++) {
+            if (h->xstage[i]) { (void)hipFree(h->xstage[i]); h->xstage[i] = nullptr; }
+            if (h->xstage_b[i]) { (void)hipFree(h->xstage_b[i]); h->xstage_b[i] = nullptr; }
+        }
+        h->plan_note = std::string("two-launch path not taken: ") + what;
+    };
+    if (hipMalloc(reinterpret_cast<void **>(&h->slabs), sizeof(float) * n) != hipSuccess) { h->slabs = nullptr; give_up("hipMalloc of the slab buffer failed"); return; }
+    if (hipMemsetAsync(h->slabs, 0, sizeof(float) * n, h->stream) != hipSuccess) { give_up("hipMemsetAsync of the slab buffer failed"); return; }
+    for (int i = 0; i < 2; i++) {
+        const size_t xn = (size_t)h->cap_rows * h->ld[0];
+        if (h->dtype == GNN_DTYPE_BF16) {
+            if (hipMalloc(reinterpret_cast<void **>(&h->xstage_b[i]), sizeof(__bf16) * xn) != hipSuccess) { h->xstage_b[i] = nullptr; give_up("hipMalloc of a row staging buffer failed"); return; }
+        } else {
+            if (hipMalloc(reinterpret_cast<void **>(&h->xstage[i]), sizeof(float) * xn) != hipSuccess) { h->xstage[i] = nullptr; give_up("hipMalloc of a row staging buffer failed"); return; }
+        }
+    }
+    h->n_slabs = n_slabs;
     TileStepParams &t = h->tsp;
-    t = TileStepParams{};
     t.n_layers = L - 1;
     int tiles = 0;
     for (int l = 0; l < L - 1; l++) {
@@ -93,19 +121,7 @@ void plan_chain(gnn_mlp *h) {
         if (l == 0) h->ts_tiles0 = tiles;
     }
     h->ts_tiles = tiles;
-    const size_t n = (size_t)h->n_slabs * h->cap_rows * h->ld[1];
-    if (n >= (1ull << 30)) return; // middle4 addresses the slabs with 32-bit byte offsets
-    if (hipMalloc(reinterpret_cast<void **>(&h->slabs), sizeof(float) * n) != hipSuccess) { (void)hipGetLastError(); h->slabs = nullptr; return; }
-    if (hipMemsetAsync(h->slabs, 0, sizeof(float) * n, h->stream) != hipSuccess) { (void)hipGetLastError(); return; }
     t.slabs = h->slabs; t.slab_rows = h->cap_rows; t.ldz = h->ld[1];
-    for (int i = 0; i < 2; i++) {
-        const size_t xn = (size_t)h->cap_rows * h->ld[0];
-        if (h->dtype == GNN_DTYPE_BF16) {
-            if (hipMalloc(reinterpret_cast<void **>(&h->xstage_b[i]), sizeof(__bf16) * xn) != hipSuccess) { (void)hipGetLastError(); h->xstage_b[i] = nullptr; return; }
-        } else {
-            if (hipMalloc(reinterpret_cast<void **>(&h->xstage[i]), sizeof(float) * xn) != hipSuccess) { (void)hipGetLastError(); h->xstage[i] = nullptr; return; }
-        }
-    }
     h->chain = true;
 }
 

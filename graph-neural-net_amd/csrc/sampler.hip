@@ -38,7 +38,7 @@ struct gnn_sampler {
 
 extern "C" {
 
-int gnn_sampler_create(int32_t master_size, int64_t seed, gnn_sampler_t **out) {
+int gnn_sampler_create(int32_t master_size, int64_t seed, gnn_sampler_t **out) { return guarded([&]() -> int {
     if (!out || master_size <= 0) return fail(GNN_ERR_BAD_ARG, "bad sampler arguments");
     gnn_sampler *s = new gnn_sampler();
     s->master = master_size;
@@ -47,11 +47,11 @@ int gnn_sampler_create(int32_t master_size, int64_t seed, gnn_sampler_t **out) {
     s->refill();
     *out = s;
     return GNN_OK;
-}
+}); }
 
 int gnn_sampler_destroy(gnn_sampler_t *s) { delete s; return GNN_OK; }
 
-int gnn_sampler_sample(gnn_sampler_t *s, int batch, int32_t *out_idx, int *n_out) {
+int gnn_sampler_sample(gnn_sampler_t *s, int batch, int32_t *out_idx, int *n_out) { return guarded([&]() -> int {
     if (!s || !out_idx || !n_out || batch <= 0) return fail(GNN_ERR_BAD_ARG, "bad sampler arguments");
     int n = 0;
     for (int i = 0; i < batch; i++) {
@@ -64,10 +64,10 @@ int gnn_sampler_sample(gnn_sampler_t *s, int batch, int32_t *out_idx, int *n_out
     }
     *n_out = n;
     return GNN_OK;
-}
+}); }
 
 int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step, double momentum,
-                          int noise) {
+                          int noise) { return guarded([&]() -> int {
     TRY(check_handle(h));
     if (!s) return fail(GNN_ERR_BAD_ARG, "null sampler");
     TRY(check_step_args(h, batch, step, noise));
@@ -81,52 +81,85 @@ int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int ba
     // chunk, while this thread uploads finished chunks and enqueues their steps.  The first chunks are short
     // (16, 32, 64, 128, then 256 iterations): nothing runs on the GPU until the first one is sampled, and a 256-batch
     // first chunk kept it idle for 2.5 ms (0.85 us per step of a 3 000-step call).
-    std::vector<int> bounds{0};
-    for (int sz = 16; bounds.back() < iterations; sz = std::min(256, sz * 2)) bounds.push_back(std::min(iterations, bounds.back() + sz));
-    const int n_chunks = (int)bounds.size() - 1;
-    std::vector<int32_t> idx((size_t)iterations * batch);
-    std::vector<int> cnt((size_t)iterations);
-    std::mutex mu;
-    std::condition_variable cv;
-    int ready = 0, sampler_rc = GNN_OK; // chunks sampled so far (guarded by mu)
-    std::string sampler_msg;
+    // Index storage is a RING of kRing chunk slots on the host and on the device, whatever the run length (NNT:62 runs
+    // 500 000 iterations): the sampler waits for a free host slot; a device slot is rewritten by a copy that is enqueued on
+    // the handle's stream behind the steps that read it.
+    static constexpr int kRing = 4, kChunk = 256;
+    auto chunk_begin = [](int c) { // 0, 16, 48, 112, 240, 496, 752, ..
+        int b = 0, sz = 16;
+        for (int i = 0; i < c; i++) { b += sz; sz = std::min(kChunk, sz * 2); if (sz == kChunk && i + 1 < c) { b += (c - i - 1) * kChunk; break; } }
+        return b;
+    };
+    int n_chunks = 0;
+    while (chunk_begin(n_chunks) < iterations) n_chunks++;
+    auto chunk_end = [&](int c) { return std::min(iterations, chunk_begin(c + 1)); };
+    const size_t slot_elems = (size_t)kChunk * batch;
+    std::vector<int32_t> idx(slot_elems * kRing);
+    std::vector<int> cnt((size_t)kChunk * kRing);
+    struct Shared {
+        std::mutex mu;
+        std::condition_variable cv;
+        int ready = 0, consumed = 0, sampler_rc = GNN_OK; // chunks sampled / chunks whose host slot is free again
+        bool stop = false;
+        std::string sampler_msg;
+    } sh;
     std::thread producer([&]() {
         for (int c = 0; c < n_chunks; c++) {
+            {
+                std::unique_lock<std::mutex> lk(sh.mu);
+                sh.cv.wait(lk, [&] { return sh.stop || c < sh.consumed + kRing; });
+                if (sh.stop) return;
+            }
             int rc = GNN_OK;
-            const int i1 = bounds[c + 1];
-            for (int i = bounds[c]; i < i1 && rc == GNN_OK; i++) rc = gnn_sampler_sample(s, batch, idx.data() + (size_t)i * batch, &cnt[i]);
-            std::lock_guard<std::mutex> lk(mu);
-            if (rc != GNN_OK) { sampler_rc = rc; sampler_msg = gnn_mlp_last_error(); ready = n_chunks; cv.notify_all(); return; }
-            ready = c + 1;
-            cv.notify_all();
+            const int i0 = chunk_begin(c), i1 = chunk_end(c);
+            int32_t *slot = idx.data() + (size_t)(c % kRing) * slot_elems;
+            int *scnt = cnt.data() + (size_t)(c % kRing) * kChunk;
+            for (int i = i0; i < i1 && rc == GNN_OK; i++) rc = gnn_sampler_sample(s, batch, slot + (size_t)(i - i0) * batch, &scnt[i - i0]);
+            std::lock_guard<std::mutex> lk(sh.mu);
+            if (rc != GNN_OK) { sh.sampler_rc = rc; sh.sampler_msg = gnn_mlp_last_error(); sh.ready = n_chunks; sh.cv.notify_all(); return; }
+            sh.ready = c + 1;
+            sh.cv.notify_all();
         }
     });
-    int32_t *d_idx = nullptr;
-    int rc = GNN_OK;
-    if (hipMalloc((void **)&d_idx, idx.size() * sizeof(int32_t)) != hipSuccess) rc = fail(GNN_ERR_HIP, "hipMalloc of the index buffer failed");
+    struct Joiner { // the worker is joined on EVERY exit path, an exception included (a joinable std::thread's destructor terminates)
+        std::thread &t; Shared &sh;
+        ~Joiner() {
+            { std::lock_guard<std::mutex> lk(sh.mu); sh.stop = true; }
+            sh.cv.notify_all();
+            if (t.joinable()) t.join();
+        }
+    } joiner{producer, sh};
+    DevScratch dbuf;
+    int rc = dbuf.alloc(slot_elems * kRing * sizeof(int32_t));
+    int32_t *d_idx = dbuf.as<int32_t>();
     for (int c = 0; c < n_chunks && rc == GNN_OK; c++) {
         {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return ready > c; });
-            if (sampler_rc != GNN_OK) { rc = fail(sampler_rc, sampler_msg); break; }
+            std::unique_lock<std::mutex> lk(sh.mu);
+            sh.cv.wait(lk, [&] { return sh.ready > c; });
+            if (sh.sampler_rc != GNN_OK) { rc = fail(sh.sampler_rc, sh.sampler_msg); break; }
         }
-        const int i0 = bounds[c], i1 = bounds[c + 1];
-        // (pageable hipMemcpyAsync returns once the host data has been consumed)
-        const hipError_t e = hipMemcpyAsync(d_idx + (size_t)i0 * batch, idx.data() + (size_t)i0 * batch,
-                                            (size_t)(i1 - i0) * batch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+        const int i0 = chunk_begin(c), i1 = chunk_end(c);
+        const size_t so = (size_t)(c % kRing) * slot_elems;
+        std::vector<int> ccnt(cnt.begin() + (size_t)(c % kRing) * kChunk, cnt.begin() + (size_t)(c % kRing) * kChunk + (i1 - i0));
+        // (pageable hipMemcpyAsync returns once the host data has been consumed: the host slot is then free for the sampler)
+        const hipError_t e = hipMemcpyAsync(d_idx + so, idx.data() + so, (size_t)(i1 - i0) * batch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
         if (e != hipSuccess) { rc = fail(GNN_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); break; }
+        {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.consumed = c + 1;
+        }
+        sh.cv.notify_all();
         for (int i = i0; i < i1 && rc == GNN_OK; i++) {
             if (h->chain && i + 1 < i1) { // the next draw of this chunk is already on the device
-                h->have_next = true; h->next_a0 = h->DX; h->next_idx = d_idx + (size_t)(i + 1) * batch; h->next_B = cnt[i + 1];
+                h->have_next = true; h->next_a0 = h->DX; h->next_idx = d_idx + so + (size_t)(i + 1 - i0) * batch; h->next_B = ccnt[i + 1 - i0];
             }
-            rc = step_on_device_indices(h, d_idx + (size_t)i * batch, cnt[i], step, momentum);
+            rc = step_on_device_indices(h, d_idx + so + (size_t)(i - i0) * batch, ccnt[i - i0], step, momentum);
         }
     }
-    producer.join(); // (on an early exit the sampler still finishes its draws: its state stays well defined)
-    (void)hipStreamSynchronize(h->stream); // idx (host) and d_idx are released below
+    // (on an early exit the sampler stops after the chunk it is drawing: its state stays well defined)
+    (void)hipStreamSynchronize(h->stream); // the device ring is released below
     h->slab_valid = false; h->have_next = false; // (they may name rows through d_idx)
-    if (d_idx) (void)hipFree(d_idx);
     return rc;
-}
+}); }
 
 } // extern "C"

@@ -132,6 +132,13 @@ class GraphedSteps:
         stream.synchronize()
         net = stepper.engine.net
         t_before = net.time
+        # The captured sequence must not depend on what ran before it: on the two-launch path a gradient computation
+        # skips its chain-start launch when the handle believes the previous step already made this batch's first-layer
+        # sums.  Forgetting that here puts the chain start INTO the graph; forgetting it again after the capture (the
+        # bookkeeping then describes steps that were enqueued, not run) and after every replay keeps eager steps that
+        # follow correct as well.
+        self._forget = getattr(net, "forget_lookahead", lambda: None)
+        self._forget()
         try:
             with torch.cuda.graph(self.graph, stream=stream):
                 for f, fn in zip(firsts, nxt):
@@ -144,14 +151,17 @@ class GraphedSteps:
             # (round 1), so nothing is repaired here: only the host-side step counter is put back,
             # and the caller is told to stop using this process for GPU work.
             net.advance_time(t_before - net.time)
+            self._forget()
             raise CaptureFailed("%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")) from e
         net.advance_time(-self.n)                 # the capture pass enqueued, it did not run
+        self._forget()
         self.eager_steps = self.n                 # steps really executed by the warm pass
 
     def replay(self):
         with self.torch.cuda.stream(self.stream):
             self.graph.replay()
         self.stepper.engine.net.advance_time(self.n)
+        self._forget()
 
 
 class LoopbackGroup:

@@ -259,6 +259,10 @@ class NeuralNet:
     def synchronize(self):
         _capi.check(self._lib.gnn_mlp_synchronize(self._h))
 
+    def forget_lookahead(self):
+        """Drop the first-layer sums made ahead for the next batch and any pending hint (results unchanged)."""
+        _capi.check(self._lib.gnn_mlp_forget_lookahead(self._h))
+
     def advance_time(self, steps):
         _capi.check(self._lib.gnn_mlp_advance_time(self._h, int(steps)))
 
@@ -281,6 +285,12 @@ class NeuralNet:
     def step_launches(self):
         """2 two-launch path, 3 fused three-launch path, 0 per-layer GEMMs."""
         return self._lib.gnn_mlp_step_launches(self._h)
+
+    @property
+    def plan_note(self):
+        """Why the net is not on the two-launch path ('' when it is)."""
+        s = self._lib.gnn_mlp_plan_note(self._h)
+        return s.decode() if s else ""
 
     # -- measurement --------------------------------------------------------------------------
     def timing_enable(self, on=True):

@@ -204,6 +204,13 @@ int gnn_mlp_synchronize(gnn_mlp_t *h);
  * gnn_mlp_set_stream) replays device work the host-side `time` counter (SCE:343) does not see;
  * it reports the replayed steps here (and takes back, with a negative count, the steps that
  * were only captured, not executed). */
+/* Drops what the handle remembers about work done AHEAD of the next gradient computation (the next batch's first-layer
+ * sums made by the previous step's tile kernel, a pending gnn_mlp_hint_next_range).  The next gradient computation then
+ * starts its own chain: results are unchanged (bitwise), one extra launch.  A caller that captures
+ * gnn_mlp_compute_gradient_range / gnn_mlp_apply_update into a HIP graph itself MUST call this before the capture begins
+ * (so that the captured sequence does not depend on what ran before it), after it ends, and after every replay (the host
+ * bookkeeping describes the captured pass, not what the device then holds); gnn_mlp_train_range does so by itself. */
+int gnn_mlp_forget_lookahead(gnn_mlp_t *h);
 int gnn_mlp_advance_time(gnn_mlp_t *h, int steps);
 /* After a stream capture that FAILED (e.g. a collective that cannot be captured invalidated it):
  * ends a capture still open on the handle's stream, discards its graph and clears the sticky HIP
@@ -262,6 +269,9 @@ int gnn_mlp_specialization(const gnn_mlp_t *h);
  * (row-block kernel + tile-owner kernel, csrc/tile_step_kernel.h), 3 = first layer / row-block kernel /
  * gradient+update, 0 = per-layer GEMMs (the count then depends on the layer count). */
 int gnn_mlp_step_launches(const gnn_mlp_t *h);
+/* Why gnn_mlp_step_launches() is not 2 for this net ("" when it is): the decision gnn_mlp_create took (layer count,
+ * LDS budget, slab count, a failed allocation, a GNN_MLP_* development switch).  The string lives as long as the handle. */
+const char *gnn_mlp_plan_note(const gnn_mlp_t *h);
 
 /* ---- measurement support (bench.py) -------------------------------------------------------
  * Mean duration in microseconds of the kernel class `which` over the launches since the last

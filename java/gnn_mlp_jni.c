@@ -37,6 +37,22 @@ static jint *copy_ints(JNIEnv *env, jintArray a, jsize *n_out) {
     if (n_out) *n_out = n;
     return p;
 }
+/* Array lengths are checked HERE against what the C call will touch (the library sees plain pointers): a short array
+ * is an IllegalArgumentException, as the reference's asserts / ArrayIndexOutOfBounds would be, never a heap overrun. */
+static int len_ok(JNIEnv *env, jarray a, long long need, const char *what) {
+    if (!a) { (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/NullPointerException"), what); return 0; }
+    if (need < 0 || (long long)(*env)->GetArrayLength(env, a) != need) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), what);
+        return 0;
+    }
+    return 1;
+}
+static int rows_ok(JNIEnv *env, gnn_mlp_t *h, jint b, jdoubleArray x, jdoubleArray y) {
+    if (!h || b <= 0) { (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), "handle / batch"); return 0; }
+    if (!len_ok(env, x, (long long)b * gnn_mlp_input_dim(h), "rows: length must be b * getInputDim()")) return 0;
+    if (y && !len_ok(env, y, (long long)b * gnn_mlp_output_dim(h), "expected: length must be b * getOutputDim()")) return 0;
+    return 1;
+}
 #define H(h) ((gnn_mlp_t *)(intptr_t)(h))
 #define DP(h) ((gnn_mlp_dp_t *)(intptr_t)(h))
 
@@ -80,6 +96,7 @@ JNIEXPORT jlong JNICALL Java_HipNeuralNet_nativeNumParams(JNIEnv *env, jclass c,
 JNIEXPORT jint JNICALL Java_HipNeuralNet_nativeTime(JNIEnv *env, jclass c, jlong h) { return (jint)gnn_mlp_time(H(h)); }
 
 JNIEXPORT void JNICALL Java_HipNeuralNet_nativePropagate(JNIEnv *env, jclass c, jlong h, jdoubleArray x, jint b, jdoubleArray out) {
+    if (!rows_ok(env, H(h), b, x, NULL) || !len_ok(env, out, (long long)b * gnn_mlp_output_dim(H(h)), "out: length must be b * getOutputDim()")) return;
     double *px = copy_doubles(env, x, NULL);
     if (!px) return;
     jsize no = (*env)->GetArrayLength(env, out);
@@ -92,6 +109,7 @@ JNIEXPORT void JNICALL Java_HipNeuralNet_nativePropagate(JNIEnv *env, jclass c, 
 }
 
 JNIEXPORT void JNICALL Java_HipNeuralNet_nativeArgmax(JNIEnv *env, jclass c, jlong h, jdoubleArray x, jint b, jintArray labels) {
+    if (!rows_ok(env, H(h), b, x, NULL) || !len_ok(env, labels, b, "labels: length must be b")) return;
     double *px = copy_doubles(env, x, NULL);
     if (!px) return;
     int32_t *pl = (int32_t *)malloc(sizeof(int32_t) * (size_t)(b > 0 ? b : 1));
@@ -103,6 +121,7 @@ JNIEXPORT void JNICALL Java_HipNeuralNet_nativeArgmax(JNIEnv *env, jclass c, jlo
 }
 
 JNIEXPORT void JNICALL Java_HipNeuralNet_nativeLoss(JNIEnv *env, jclass c, jlong h, jdoubleArray x, jdoubleArray y, jint b, jdoubleArray loss) {
+    if (!rows_ok(env, H(h), b, x, y) || !len_ok(env, loss, b, "loss: length must be b")) return;
     double *px = copy_doubles(env, x, NULL);
     if (!px) return;
     double *py = copy_doubles(env, y, NULL);
@@ -116,6 +135,7 @@ JNIEXPORT void JNICALL Java_HipNeuralNet_nativeLoss(JNIEnv *env, jclass c, jlong
 }
 
 JNIEXPORT void JNICALL Java_HipNeuralNet_nativeWeightGradient(JNIEnv *env, jclass c, jlong h, jdoubleArray x, jdoubleArray y, jint b, jdoubleArray flat) {
+    if (!rows_ok(env, H(h), b, x, y)) return;
     double *px = copy_doubles(env, x, NULL);
     if (!px) return;
     double *py = copy_doubles(env, y, NULL);
@@ -131,11 +151,12 @@ JNIEXPORT void JNICALL Java_HipNeuralNet_nativeWeightGradient(JNIEnv *env, jclas
 
 JNIEXPORT void JNICALL Java_HipNeuralNet_nativeGradientStep(JNIEnv *env, jclass c, jlong h, jdoubleArray x, jdoubleArray y, jint b,
         jdouble step, jdouble momentum, jboolean noise) {
+    if (!rows_ok(env, H(h), b, x, y)) return;
     double *px = copy_doubles(env, x, NULL);
     if (!px) return;
     double *py = copy_doubles(env, y, NULL);
     if (!py) { free(px); return; }
-    /* the call returns once the host rows have been consumed (pageable hipMemcpyAsync), so the copies can go */
+    /* the call returns once the host rows have been consumed (rounded into the library's pinned slot), so the copies can go */
     int rc = gnn_mlp_gradient_step(H(h), px, py, b, step, momentum, noise ? 1 : 0);
     free(px); free(py);
     if (rc) throw_status(env, rc);
@@ -143,6 +164,9 @@ JNIEXPORT void JNICALL Java_HipNeuralNet_nativeGradientStep(JNIEnv *env, jclass 
 
 JNIEXPORT void JNICALL Java_HipNeuralNet_nativeGradientStepDp(JNIEnv *env, jclass c, jlong dp, jdoubleArray x, jdoubleArray y, jint b,
         jdouble step, jdouble momentum, jboolean noise) {
+    gnn_mlp_t *r0 = NULL;
+    if (gnn_mlp_dp_replica(DP(dp), 0, &r0)) { throw_status(env, GNN_ERR_BAD_ARG); return; }
+    if (!rows_ok(env, r0, b, x, y)) return;
     double *px = copy_doubles(env, x, NULL);
     if (!px) return;
     double *py = copy_doubles(env, y, NULL);
