@@ -50,7 +50,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 den
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF figure is 2:1 sparse)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 EXIT_CAPTURE_FAILED = 75       # a rank's stream capture did not produce a graph: rerun eager in fresh processes
-PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03", "pmc_traffic.json")
+MFMA_FILE = os.path.join("profiles", "r03", "mfma_counters.json")
 
 
 def parse_args(argv=None):
@@ -61,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="GEMM operand type (f32 = BASELINE configs[1], the headline; bf16 = configs[2]'s arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short same-run timings of BASELINE configs[0], [3], [4] (N=1 only; a few seconds)")
     ap.add_argument("--dp-mode", choices=["auto", "graph", "eager"], default="auto",
                     help="data-parallel path: hipGraph replay of the resident batches, or eager steps; "
                          "auto = eager on more than one rank, graph for the one-rank --dp-path with RCCL")
@@ -191,6 +194,45 @@ def pmc_traffic(kernel_substring):
     return None
 
 
+def mfma_counter(kernel_substring):
+    """MFMA-pipe utilisation of a kernel from the committed rocprofv3 counter pass over this very command
+    (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs), tools/mfma_summary.py): the counter figure
+    that stands beside FLOP / time / peak.  Null when the file has no kernel of that name."""
+    try:
+        with open(os.path.join(ROOT, MFMA_FILE)) as f:
+            for name, d in json.load(f)["kernels"].items():
+                if kernel_substring in name:
+                    return d["mfma_util"]
+    except Exception:
+        pass
+    return None
+
+
+def other_configs():
+    """Short same-run timings of the BASELINE configs bench.py's headline is NOT quoted on, so that the driver's line
+    carries them: configs[0] (the reference's CPU-runnable case), configs[3] (f32 and bf16), configs[4] (f32 eager and
+    under the hipGraph-captured step BASELINE names, bf16).  tools/bench_configs.py holds the accounting."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+    out = {}
+    for name, key, dtype, steps, graph in [("configs[0] f32", "1", "f32", 1000, False),
+                                           ("configs[3] f32", "4", "f32", 30, False), ("configs[3] bf16", "4", "bf16", 50, False),
+                                           ("configs[4] f32 eager", "5", "f32", 80, False),
+                                           ("configs[4] f32 hipGraph", "5", "f32", 160, True),
+                                           ("configs[4] bf16", "5", "bf16", 80, False)]:
+        try:
+            line = bc.run(key, dtype, steps, graph=graph, n_batches=4, timed_kernels=False)
+            r = line["roofline"]
+            out[name] = {"workload": line["config"]["workload"], "samples_per_s": line["value"], "us_per_step": round(line["ms_per_step"] * 1e3, 2),
+                         "us_per_step_events": line.get("us_per_step_events"), "steps": steps, "dtype": dtype,
+                         "hipgraph": graph, "bound": r["bound"], "mfma_frac": r["mfma_frac"], "hbm_frac": r["hbm_frac"]}
+        except Exception as e:   # a config that fails must not take the headline down with it
+            out[name] = {"error": "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0])}
+    return out
+
+
 def synthetic(n, seed):
     """X ~ U[0,1) 784-dim, uniform one-hot labels; generated here, never shipped."""
     import numpy as np
@@ -304,6 +346,10 @@ def worker(args, argv):
 
     graphed = None
     if dist is None:
+        # the net's kernels on a torch stream, so that torch events bracket the timed region ON THE LAUNCH STREAM
+        side = torch.cuda.Stream()
+        net.set_stream(side.cuda_stream)
+
         def run(first_batch, n, eager=False):
             net.train_range((first_batch % N_BATCHES) * BATCH, BATCH, n, STEP, MOMENTUM)
     else:
@@ -361,10 +407,14 @@ def worker(args, argv):
 
     run(0, W)
     barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(side)
     run(0 if dist is not None else W, K)  # data parallel: start on a graph boundary (the resident batches)
+    ev1.record(side)
     barrier()
     dt = time.perf_counter() - t0
+    dt_events = ev0.elapsed_time(ev1) * 1e-3   # the same K steps between two events on the stream the kernels run on
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -450,6 +500,7 @@ def worker(args, argv):
                     "mfma_frac": round(flop / (us * 1e-6) / 1e12 / mfma_peak, 4),
                     "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                     "share_of_step": round(us * n / (step_us * nt), 3),
+                    "mfma_util_counter": None if is_dp or bf16 else next((v for v in map(mfma_counter, pmc_key[k]) if v is not None), None),
                     "traffic": None if is_dp or bf16 else next((v for v in map(pmc_traffic, pmc_key[k]) if v is not None), None)}
         if kernels:
             # roofline kernel = the one with the largest share of the step's time.  Which roof: its
@@ -466,6 +517,9 @@ def worker(args, argv):
                         "frac": round(ach / peak, 4), "traffic": e["traffic"],
                         "traffic_source": PMC_FILE if e["traffic"] is not None else None,
                         "avg_launch_us": e["avg_us"], "launches": e["launches"],
+                        # the MFMA pipe's busy share by COUNTER (rocprofv3 pass in profiles/, same command), beside FLOP/time/peak
+                        "mfma_util_counter": None if is_dp or bf16 else next((v for v in map(mfma_counter, pmc_key[dom]) if v is not None), None),
+                        "mfma_util_counter_source": MFMA_FILE,
                         "algorithmic_bytes_per_launch": e["algorithmic_bytes"], "flop_per_launch": e["flop"],
                         "arithmetic_intensity_flop_per_byte": round(ai, 2), "ridge_flop_per_byte": round(ridge, 1),
                         "share_of_step": e["share_of_step"],
@@ -497,6 +551,11 @@ def worker(args, argv):
             if not args.no_cpu_baseline:
                 cpu = cpu_baseline()
 
+    others = None
+    if rank == 0 and dist is None and not args.no_other_configs:
+        net.close()
+        others = other_configs()
+
     lockstep = None
     if dist is not None:
         # every rank applied the same all-reduced gradient: the replicas must hold identical weights
@@ -511,6 +570,7 @@ def worker(args, argv):
             "value": round(total / dt, 1), "unit": "samples/s",
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 5),
+            "ms_per_step_events": round(dt_events / K * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "host_batch_samples_per_s": host_rate,
@@ -527,6 +587,7 @@ def worker(args, argv):
                        "step": STEP, "momentum": MOMENTUM, "inner_activation": "leaky_relu"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "other_configs": others,
         }
         emit(json.dumps(line))
 

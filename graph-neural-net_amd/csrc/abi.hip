@@ -416,9 +416,15 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
     // very stream and replayed with a single launch per pass; the remainder runs eagerly.  It is
     // off by default because it buys nothing on one GPU (22.38 vs 22.32 us/step: the kernels
     // already run back to back) while the capture costs a few ms on the first call.  Never while
-    // per-kernel timing is on (timed launches carry events) or on a caller-provided stream (the
-    // caller may be capturing itself).
-    const bool want_graph = h->env_graph && !h->timing && h->stream == h->own_stream &&
+    // per-kernel timing is on (timed launches carry events) or on a caller-provided stream that is
+    // itself being captured.
+    bool caller_capturing = false; // (a caller-provided stream may itself be under capture: never nest)
+    if (h->env_graph && h->stream != h->own_stream) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        caller_capturing = hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+        if (caller_capturing) (void)hipGetLastError();
+    }
+    const bool want_graph = h->env_graph && !h->timing && !caller_capturing &&
                             nb >= 2 && nb <= 1024 && n_steps >= 2 * nb;
     if (want_graph) {
         const int64_t fb = (first / B) % nb;

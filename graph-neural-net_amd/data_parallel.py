@@ -170,7 +170,8 @@ class LoopbackGroup:
     get_rank, barrier, ReduceOp).  It exists so that the sharding + reduction + lock-step logic can be
     run at world sizes 4 and 8 where there are neither 8 GPUs nor a process group; the
     sum is taken in RANK ORDER, like the library's direct reducer, so every rank gets the same bits.
-    Works on numpy arrays and on anything with .numpy() / .copy_() (CPU torch tensors)."""
+    Works on numpy arrays and on torch tensors (CPU, or device tensors, which cross through the host: that is how
+    the GPU engine is run at world 8 on a one-GPU box, eight ranks as threads of one process)."""
 
     class ReduceOp:
         SUM, MIN, MAX = "sum", "min", "max"
@@ -228,7 +229,11 @@ class _LoopbackRank:
 
     def all_reduce(self, tensor, op="sum", group=None):
         g = self.group
-        arr = tensor.numpy() if hasattr(tensor, "numpy") else np.asarray(tensor)
+        on_device = bool(getattr(tensor, "is_cuda", False))
+        if on_device:   # a device tensor: through the host (`.cpu()` waits for the work enqueued before it on the current stream)
+            arr = tensor.detach().cpu().numpy()
+        else:
+            arr = tensor.numpy() if hasattr(tensor, "numpy") else np.asarray(tensor)
         g._slots[self.rank] = np.array(arr, copy=True)
         g._bar.wait()                                   # every rank's contribution is in
         acc = g._slots[0].copy()
@@ -242,6 +247,6 @@ class _LoopbackRank:
         g._bar.wait()                                   # nobody overwrites a slot another rank still reads
         if hasattr(tensor, "copy_"):
             import torch
-            tensor.copy_(torch.from_numpy(acc))
+            tensor.copy_(torch.from_numpy(acc))   # (device tensors: an H2D copy on the caller's current stream)
         else:
             arr[...] = acc

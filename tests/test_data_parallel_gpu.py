@@ -108,3 +108,45 @@ def test_two_ranks_one_gpu_equal_single_process(gnn, tmp_path, bf16):
         # the data-parallel replicas themselves after 3 global steps (tests/test_bf16_gpu.py allows one GPU 2e-4
         # after 3 steps; the two partial sums add their own reordering)
         assert np.abs(np.load(tmp_path / "w0_s3.npy") - w).max() <= 3e-4
+
+
+@pytest.mark.timeout(300)
+def test_config3_world8_one_process_per_gpu_form_on_one_gpu(gnn):
+    """BASELINE configs[2] at its stated split through the one-process-per-GPU code (HipEngine + DataParallelStep):
+    world 8, 128 rows per rank, global batch 1024, bf16 operands.  The box's process guard allows six GPU processes, so
+    the eight ranks are eight THREADS of this process (LoopbackGroup: each with its own net, stream and gradient tensor
+    on cuda:0; the rank-ordered sum crosses the host).  What differs from `bench.py --gpus 8` is the collective's
+    transport only.  Replicas bitwise identical; equal to the bf16-aware fp64 restatement on the global batch."""
+    import torch
+    from gnn_amd import data_parallel as dp
+    from tests import np_oracle
+    world, B_local, steps = 8, 128, 3
+    Bg = world * B_local
+    rng = np.random.default_rng(77)
+    X = rng.random((Bg * steps, DIMS[0])) * (rng.random((Bg * steps, DIMS[0])) < 0.3)
+    Y = np.eye(DIMS[-1])[rng.integers(0, DIMS[-1], Bg * steps)]
+    group = dp.LoopbackGroup(world)
+
+    def rank_body(rank, dist):
+        rows = np.concatenate([np.arange(s * Bg + rank * B_local, s * Bg + (rank + 1) * B_local) for s in range(steps)])
+        net = gnn.SoftmaxCrossEntropyNeuralNet(DIMS, device=0, max_batch=B_local, dtype=gnn.DTYPE_BF16)
+        net.upload_dataset(X[rows], Y[rows])
+        stepper = dp.DataParallelStep(dp.HipEngine(net, torch), dist)
+        assert stepper.world == world and stepper.rank == rank
+        for s in range(steps):
+            nxt = (s + 1) * B_local if s + 1 < steps else None
+            stepper.step(s * B_local, B_local, 0.0125, 0.9, next_first=nxt)
+        net.synchronize()
+        assert net.time == steps
+        return net.get_weights(), net.get_momentum()
+
+    out = group.run(rank_body)
+    for w_r, v_r in out[1:]:
+        assert np.array_equal(w_r, out[0][0]) and np.array_equal(v_r, out[0][1])
+    ini = gnn.SoftmaxCrossEntropyNeuralNet(DIMS, max_batch=16)
+    w, v = ini.get_weights(), np.zeros(ini.n_params)
+    X32 = X.astype(np.float32).astype(np.float64)
+    for s in range(steps):
+        w, v = np_oracle.gradient_step_bf16(w, v, DIMS, X32[s * Bg:(s + 1) * Bg], Y[s * Bg:(s + 1) * Bg], 0.0125, 0.9, 0)
+    assert np.abs(out[0][0] - w).max() <= 3e-4
+    assert np.abs(out[0][1] - v).max() <= 3e-4

@@ -90,3 +90,33 @@ def test_direct_reducer_bf16(gnn):
     assert net.replicas_identical()
     ref = single_net_reference(gnn, X, Y, B, steps, gnn.DTYPE_BF16)
     assert np.abs(net.get_weights() - ref.get_weights()).max() <= 3e-4
+
+
+def test_config3_eight_way_global_batch_1024_bf16(gnn):
+    """BASELINE configs[2] AS STATED, on the one GPU there is: 784-300-100-10, bf16 operands, 8-way data parallel,
+    global batch 1024 (128 rows per replica), the eight replicas sharing device 0 behind ONE handle (the direct
+    reducer: peer pointers, cross-stream events, rank-ordered sum).  Replicas bitwise identical; weights equal to the
+    bf16-aware fp64 restatement of gradientStep on the GLOBAL batch (SCE:297-346 with every GEMM operand rounded to
+    bf16).  RCCL needs eight distinct devices, and the box's process guard allows six GPU processes: those legs are
+    the driver's 8-GPU run."""
+    from tests import np_oracle
+    Bg, steps = 1024, 3
+    X, Y = data(Bg * steps, seed=31)
+    net = gnn.DataParallelNeuralNet(DIMS, devices=[0] * 8, max_batch=Bg, reducer=gnn.REDUCE_DIRECT, dtype=gnn.DTYPE_BF16)
+    assert len(net.replicas) == 8
+    w, v = net.get_weights(), np.zeros(net.n_params)
+    net.upload_dataset(X, Y)
+    net.train_range(0, Bg, steps, 0.0125, 0.9)
+    net.synchronize()
+    assert net.time == steps and net.replicas_identical()
+    X32 = X.astype(np.float32).astype(np.float64)
+    for s in range(steps):
+        w, v = np_oracle.gradient_step_bf16(w, v, DIMS, X32[s * Bg:(s + 1) * Bg], Y[s * Bg:(s + 1) * Bg], 0.0125, 0.9, 0)
+    assert np.abs(net.get_weights() - w).max() <= 3e-4
+    assert np.abs(net.get_momentum() - v).max() <= 3e-4
+    # the same three steps through the host-batch entry point (NeuralNet.gradientStep(rows): shards of 128 rows)
+    net2 = gnn.DataParallelNeuralNet(DIMS, devices=[0] * 8, max_batch=Bg, reducer=gnn.REDUCE_DIRECT, dtype=gnn.DTYPE_BF16)
+    for s in range(steps):
+        net2.gradientStep(X[s * Bg:(s + 1) * Bg], 0.0125, 0.9, False, expected=Y[s * Bg:(s + 1) * Bg])
+    assert net2.replicas_identical()
+    assert np.array_equal(net2.get_weights(), net.get_weights())

@@ -327,6 +327,17 @@ def test_full_size_configs_properties(gnn, dims, B):
     other.compute_gradient_range(0, B)
     other.apply_update(B, 0.0125, 0.9)
     assert np.abs(net.get_weights() - other.get_weights()).max() <= 1e-7
+    # (6) ONE full-size UPDATE step against the fp64 matrix-form restatement of gradientStep (SCE:297-346): weights and
+    # momentum, every element, both the fused step and (above, equal to it) the split one.  tanh as in (5).
+    smooth.upload_dataset(X, Y)
+    smooth.gradient_step_range(0, B, 0.0125, 0.9)
+    w_ref, v_ref = np_oracle.gradient_step(w, np.zeros_like(w), dims, X, Y, 0.0125, 0.9, TANH)
+    assert smooth.time == 1
+    # the update is step/B * G: G's absolute error (5e-5 of its largest element, as in (5)) scaled the same way,
+    # plus the f32 rounding of w itself
+    tol = 0.0125 / B * 5e-5 * max(np.abs(g).max() for g in g_all.values()) + 2e-7 * np.abs(w).max() + 1e-9
+    assert np.abs(smooth.get_momentum() - v_ref).max() <= tol
+    assert np.abs(smooth.get_weights() - w_ref).max() <= tol
 
 
 def test_graph_replayed_steps_equal_eager(gnn):
@@ -355,6 +366,43 @@ def test_graph_replayed_steps_equal_eager(gnn):
     assert a.time == 3 * nb == b.time
     wa, wb = a.get_weights(), b.get_weights()
     assert np.array_equal(wa, wb)     # same kernels, same order: bitwise
+
+
+def test_graph_replay_between_eager_steps_with_hints(gnn):
+    """A captured step sequence must not depend on what ran before it, nor leave the handle believing in work the device
+    does not hold (two-launch path: the first-layer sums made AHEAD for the next batch).  bench.py's shape: a warm run
+    that does not end on the graph's first batch, replays, then eager steps on another batch -- all with next-batch
+    hints -- against the same steps run all-eager.  The chain may be cut anywhere without changing a bit."""
+    import torch
+    from gnn_amd import data_parallel as dp
+    dims, B, nb = [784, 300, 100, 10], 128, 6
+    X, Y = make_batch(dims, B * nb, seed=22)
+    firsts = [b * B for b in range(nb)]
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    assert a.step_launches == 2
+    a.upload_dataset(X, Y); b.upload_dataset(X, Y)
+    side = torch.cuda.Stream()
+    step_a = dp.DataParallelStep(dp.HipEngine(a, torch, stream=torch.cuda.Stream()))
+    step_b = dp.DataParallelStep(dp.HipEngine(b, torch, stream=side))
+    g = dp.GraphedSteps(step_b, torch, side, firsts, B, 0.0125, 0.9)          # one eager pass + the capture
+    seq = list(firsts)
+    warm = [firsts[0], firsts[1], firsts[2]]                                   # ends with the slabs of batch 3 made ahead
+    for i, f in enumerate(warm):
+        step_b.step(f, B, 0.0125, 0.9, next_first=firsts[i + 1])
+    seq += warm
+    g.replay(); g.replay()
+    seq += firsts + firsts
+    tail = [firsts[4], firsts[2], firsts[5]]
+    for i, f in enumerate(tail):
+        step_b.step(f, B, 0.0125, 0.9, next_first=tail[i + 1] if i + 1 < len(tail) else None)
+    seq += tail
+    for f in seq:                                                              # the same steps, eager, no hints
+        step_a.step(f, B, 0.0125, 0.9)
+    torch.cuda.synchronize()
+    assert a.time == len(seq) == b.time
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    assert np.array_equal(a.get_momentum(), b.get_momentum())
 
 
 @pytest.mark.parametrize("dims,B,inner", [

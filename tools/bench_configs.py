@@ -33,28 +33,50 @@ PEAK_TF = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peak
 HBM_GBS = 8000.0
 
 
-def run(key, dtype, steps):
+def run(key, dtype, steps, graph=False, n_batches=8, timed_kernels=True):
+    """graph: the hipGraph-captured training step of gnn_mlp_train_range (GNN_MLP_GRAPH=1, read at create): one pass over
+    the resident batches captured once, replayed; `steps` should then be a multiple of 2 * n_batches."""
+    import torch
     dims, B, label = CONFIGS[key]
     rng = np.random.default_rng(0)
-    nb = 8
+    nb = n_batches
     X = rng.random((B * nb, dims[0])) * (rng.random((B * nb, dims[0])) < 0.19)
     Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B * nb)]
-    net = gnn_amd.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn_amd.DTYPE_BF16 if dtype == "bf16" else gnn_amd.DTYPE_F32, max_batch=B)
+    old = os.environ.get("GNN_MLP_GRAPH")
+    os.environ["GNN_MLP_GRAPH"] = "1" if graph else "0"   # (read once, at create)
+    try:
+        net = gnn_amd.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn_amd.DTYPE_BF16 if dtype == "bf16" else gnn_amd.DTYPE_F32, max_batch=B)
+    finally:
+        if old is None:
+            del os.environ["GNN_MLP_GRAPH"]
+        else:
+            os.environ["GNN_MLP_GRAPH"] = old
     if dims[0] > 1000 or len(dims) > 4:
         net.set_weights(net.get_weights() * 0.05)   # keep the softmax unsaturated at these widths
     net.upload_dataset(X, Y)
-    net.train_range(0, B, 20, 0.0125, 0.9)
+    side = torch.cuda.Stream()
+    net.set_stream(side.cuda_stream)
+    net.train_range(0, B, max(20, 2 * nb), 0.0125, 0.9)   # (under `graph` this captures the pass and replays it once)
+    net.synchronize()
+    # wall clock AND two events on the stream the kernels are launched on (a torch stream bound to the handle)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     net.synchronize()
     t0 = time.perf_counter()
+    e0.record(side)
     net.train_range(0, B, steps, 0.0125, 0.9)
+    e1.record(side)
     net.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    net.timing_enable(True)
-    net.train_range(0, B, min(steps, 100), 0.0125, 0.9)
-    net.synchronize()
-    fwd_us, fwd_n = net.timing_read(0)
-    grad_us, grad_n = net.timing_read(1)
-    net.timing_enable(False)
+    dt_ev = e0.elapsed_time(e1) * 1e-3 / steps
+    fwd_us = grad_us = 0.0
+    fwd_n = grad_n = 0
+    if timed_kernels:
+        net.timing_enable(True)
+        net.train_range(0, B, min(steps, 100), 0.0125, 0.9)
+        net.synchronize()
+        fwd_us, fwd_n = net.timing_read(0)
+        grad_us, grad_n = net.timing_read(1)
+        net.timing_enable(False)
     P = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1))
     flop = (6 * P - 2 * dims[0] * dims[1]) * B
     eo = 2 if dtype == "bf16" else 4
@@ -77,8 +99,8 @@ def run(key, dtype, steps):
             "avg_us": round(grad_us, 2), "launches": grad_n, "tflops": round(f / (grad_us * 1e-6) / 1e12, 2),
             "mfma_frac": round(f / (grad_us * 1e-6) / 1e12 / PEAK_TF[dtype], 4)}
     line = {"metric": "training samples/sec, %s" % label, "value": round(B / dt, 1), "unit": "samples/s", "n_gpus": 1,
-            "steps": steps, "ms_per_step": round(dt * 1e3, 5), "dtype": dtype, "data": "synthetic",
-            "config": {"workload": label, "dims": dims, "batch": B, "step_launches": net.step_launches},
+            "steps": steps, "ms_per_step": round(dt * 1e3, 5), "us_per_step_events": round(dt_ev * 1e6, 2), "dtype": dtype, "data": "synthetic",
+            "config": {"workload": label, "dims": dims, "batch": B, "step_launches": net.step_launches, "hipgraph": bool(graph)},
             "roofline": {"bound": bound, "kernel": "whole gradientStep (forward + backward GEMM chain + update)",
                          "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
                          "flop_per_step": flop, "algorithmic_bytes_per_step": nbytes,
@@ -97,12 +119,15 @@ def main():
         i = args.index("--steps")
         steps = int(args[i + 1])
         del args[i:i + 2]
+    graph = "--graph" in args
     dtypes = [a for a in args if a in ("f32", "bf16")] or ["f32"]
     which = [a for a in args if a in CONFIGS] or ["1", "2", "5", "4"]
     for key in which:
         for dtype in dtypes:
             n = steps or (200 if key in ("4", "5") else 2000)
             print(json.dumps(run(key, dtype, n)), flush=True)
+            if graph and key == "5":   # configs[4] names the hipGraph-captured step: both forms, side by side
+                print(json.dumps(run(key, dtype, n - n % 16, graph=True)), flush=True)
 
 
 if __name__ == "__main__":

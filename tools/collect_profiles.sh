@@ -11,6 +11,7 @@ cp "$SRC/stats_cfg45_f32/run_kernel_stats.csv"  "$DST/final_configs45_f32_kernel
 cp "$SRC/stats_cfg45_bf16/run_kernel_stats.csv" "$DST/final_configs45_bf16_kernel_stats.csv"
 python3 tools/pmc_summary.py "$SRC/pmc_fetch/run_counter_collection.csv" "$SRC/pmc_write/run_counter_collection.csv" > "$DST/pmc_traffic.json"
 python3 tools/sq_summary.py "$SRC/pmc_sq/run_counter_collection.csv" > "$DST/sq_counters.json"
+python3 tools/mfma_summary.py "$SRC/pmc_mfma/run_counter_collection.csv" "$SRC/pmc_mfma_cfg45/run_counter_collection.csv" > "$DST/mfma_counters.json"
 cp "$SRC/bench_default.json"      "$DST/final_bench_f32.json"
 cp "$SRC/bench_bf16.json"         "$DST/final_bench_bf16.json"
 cp "$SRC/bench_dp1_graph.json"    "$DST/final_bench_dp_path_n1_graph.json"

@@ -8,7 +8,7 @@ OUT=${1:-gpurun_out/prof_round}
 ROOT=$(pwd)
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --steps 400 --warmup 100 --no-cpu-baseline"
+B="python3 $ROOT/bench.py --steps 400 --warmup 100 --no-cpu-baseline --no-other-configs"
 run() { # name, rocprof args..., -- command
     local name=$1; shift
     timeout -k 10 300 rocprofv3 "$@" > "$ROOT/$OUT/$name.log" 2>&1 || echo "$name failed" >> "$ROOT/$OUT/failures.txt"
@@ -19,14 +19,17 @@ run stats_dp1   --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_
 run pmc_fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$ROOT/$OUT/pmc_fetch" -o run -- $B
 run pmc_write   --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$ROOT/$OUT/pmc_write" -o run -- $B
 run pmc_sq      --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d "$ROOT/$OUT/pmc_sq" -o run -- $B
+MF="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+run pmc_mfma    --kernel-trace --pmc $MF --output-format csv -d "$ROOT/$OUT/pmc_mfma" -o run -- $B
+run pmc_mfma_cfg45 --kernel-trace --pmc $MF --output-format csv -d "$ROOT/$OUT/pmc_mfma_cfg45" -o run -- python3 $ROOT/tools/bench_configs.py 4 5 f32 bf16 --steps 24
 run stats_cfg45_f32  --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_cfg45_f32"  -o run -- python3 $ROOT/tools/bench_configs.py 4 5 f32 --steps 60
 run stats_cfg45_bf16 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_cfg45_bf16" -o run -- python3 $ROOT/tools/bench_configs.py 4 5 bf16 --steps 60
 cd "$ROOT"
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-python3 bench.py --dtype bf16 --no-cpu-baseline > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"
-python3 bench.py --dp-path --no-cpu-baseline --steps 2048 --warmup 256 > "$OUT/bench_dp1_graph.json" 2> "$OUT/bench_dp1_graph.err"
-GNN_MLP_CHAIN=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_three_launch.json" 2> "$OUT/bench_three_launch.err"
-python3 tools/bench_configs.py 1 2 4 5 f32 bf16 > "$OUT/configs_all.jsonl" 2> "$OUT/configs_all.err"
+python3 bench.py --dtype bf16 --no-cpu-baseline --no-other-configs > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"
+python3 bench.py --dp-path --no-cpu-baseline --no-other-configs --steps 2048 --warmup 256 > "$OUT/bench_dp1_graph.json" 2> "$OUT/bench_dp1_graph.err"
+GNN_MLP_CHAIN=0 python3 bench.py --no-cpu-baseline --no-other-configs > "$OUT/bench_three_launch.json" 2> "$OUT/bench_three_launch.err"
+python3 tools/bench_configs.py 1 2 4 5 f32 bf16 --graph > "$OUT/configs_all.jsonl" 2> "$OUT/configs_all.err"
 python3 tools/bench_host_path.py > "$OUT/host_path.txt" 2>&1
 python3 tools/bench_trainer.py > "$OUT/trainer.txt" 2>&1
 ls -R "$OUT" | head -80
