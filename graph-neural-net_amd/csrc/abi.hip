@@ -24,6 +24,7 @@ void read_env(gnn_mlp *h) {
     h->env_static_off = is("GNN_MLP_STATIC", "0");
     h->env_chain_off = is("GNN_MLP_CHAIN", "0");
     h->env_wavek_off = is("GNN_MLP_WAVEK", "0");
+    h->env_rb_off = is("GNN_MLP_ROWBLOCK", "0");
 }
 } // namespace
 

@@ -7,6 +7,7 @@
 #include "gemm_bf16.h"
 #include "gemm_wavek.h"
 #include "middle4_kernel.h"
+#include "rowblock_kernel.h"
 #include "tile_step_kernel.h"
 #include "kernels.h"
 
@@ -73,6 +74,14 @@ struct gnn_mlp {
                                                           // (bf16 nets: only slot 2, the bf16 training kernel)
     hipFunction_t mid4_jit[3] = {nullptr, nullptr, nullptr}; // run-time instantiation (jit.h), preferred when set
 
+    // the TRAINING row-block kernel of the two-launch step (rowblock_kernel.h): f32 nets whose plan fits; else mid4_fn[2]
+    bool rb = false;
+    gnn::RbParams rbp{};
+    size_t rb_lds_bytes = 0;
+    const void *rb_fn = nullptr;
+    hipFunction_t rb_jit = nullptr; // run-time instantiation (jit.h), preferred when set
+    int rb_static = 0;              // 1: rb_fn is a prebuilt static-shape instantiation
+
     // two-launch step (tile_step_kernel.h): the tile kernel of step s also makes the first-layer K slabs of step s+1
     bool chain = false;
     gnn::TileStepParams tsp{};
@@ -114,6 +123,7 @@ struct gnn_mlp {
     bool env_jit_off = false;  // GNN_MLP_JIT=0
     bool env_static_off = false; // GNN_MLP_STATIC=0
     bool env_chain_off = false;  // GNN_MLP_CHAIN=0: three launches per step (fwd_first / middle4 / grad_update)
+    bool env_rb_off = false;     // GNN_MLP_ROWBLOCK=0: middle4_kernel<.., SLABS> as the two-launch step's row-block kernel (round 2's form)
 };
 
 namespace gnn {
@@ -250,6 +260,7 @@ void to_bf16(gnn_mlp *h, const float *src, __bf16 *dst, size_t n);
 // ---- launch_small.hip: the row-block kernel and the tile-owner kernel ----------------------------
 struct NextBatch { const float *a0; const int32_t *idx; int B; };
 void plan_mid4(gnn_mlp *h);
+void plan_rowblock(gnn_mlp *h); // (after plan_chain: the kernel exists for the two-launch step only)
 void try_specialize(gnn_mlp *h);
 void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
                    bool want_loss, bool want_label, bool from_slabs = false);

@@ -122,5 +122,48 @@ inline const Specialised *get_middle4(int device, const int *dims, int L, int ac
     return &sp;
 }
 
+// rowblock_kernel<RbStaticShape<dims...>, act, outk> (rowblock_kernel.h): the two-launch step's training kernel, fn[0].
+inline const Specialised *get_rowblock(int device, const int *dims, int L, int act, int outk, size_t lds_bytes) {
+    static std::mutex mu;
+    static std::map<std::string, Specialised> cache;
+    const std::string key = std::to_string(device) + "|" + shape_list(dims, L) + "|" + std::to_string(act) + "|" + std::to_string(outk);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second.fn[0] ? &it->second : nullptr;
+    Specialised &sp = cache[key];
+    sp.n_fn = 1;
+    const std::string expr = "gnn::rowblock_kernel<gnn::RbStaticShape<" + shape_list(dims, L) + ">, " + std::to_string(act) + ", " + std::to_string(outk) + ", false>";
+    const std::string src = "#include \"rowblock_kernel.h\"\n";
+    const char *hdr_src[] = {kEmbedded_kernels_h, kEmbedded_fused_kernels_h, kEmbedded_middle4_kernel_h, kEmbedded_rowblock_kernel_h};
+    const char *hdr_name[] = {"kernels.h", "fused_kernels.h", "middle4_kernel.h", "rowblock_kernel.h"};
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "gnn_rowblock_jit.hip", 4, hdr_src, hdr_name) != HIPRTC_SUCCESS) { sp.log = "hiprtcCreateProgram failed"; return nullptr; }
+    (void)hiprtcAddNameExpression(prog, expr.c_str());
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+    size_t ls = 0;
+    if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) { sp.log.assign(ls, '\0'); (void)hiprtcGetProgramLog(prog, &sp.log[0]); }
+    std::vector<char> code;
+    std::string name;
+    if (rc == HIPRTC_SUCCESS) {
+        const char *low = nullptr;
+        size_t cs = 0;
+        if (hiprtcGetLoweredName(prog, expr.c_str(), &low) == HIPRTC_SUCCESS && low) name = low;
+        if (!name.empty() && hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs) {
+            code.resize(cs);
+            if (hiprtcGetCode(prog, code.data()) != HIPRTC_SUCCESS) code.clear();
+        }
+    }
+    (void)hiprtcDestroyProgram(&prog);
+    if (code.empty()) return nullptr;
+    if (hipModuleLoadData(&sp.module, code.data()) != hipSuccess) { (void)hipGetLastError(); sp.log += "\nhipModuleLoadData failed"; return nullptr; }
+    if (hipModuleGetFunction(&sp.fn[0], sp.module, name.c_str()) != hipSuccess) { (void)hipGetLastError(); sp.fn[0] = nullptr; return nullptr; }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(sp.fn[0]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (lds_bytes > 64 * 1024) { sp.fn[0] = nullptr; return nullptr; }
+    }
+    return &sp;
+}
+
 } // namespace jit
 } // namespace gnn

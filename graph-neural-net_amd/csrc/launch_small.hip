@@ -94,6 +94,58 @@ void plan_mid4(gnn_mlp *h) {
     h->mid4 = true;
 }
 
+// ---- rowblock_kernel plan -----------------------------------------------------------------------
+using RbMnistA = RbStaticShape<784, 300, 100, 10>;
+using RbMnistB = RbStaticShape<784, 100, 50, 10>;
+template <class SH> const void *rb_fn_static(int act) {
+    switch (act) {
+    case 0: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 0, 0>);
+    case 1: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 1, 0>);
+    case 2: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 2, 0>);
+    case 3: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 3, 0>);
+    default: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 4, 0>);
+    }
+}
+template <int NL> const void *rb_fn_runtime(int out_kind) {
+    return out_kind == GNN_OUT_SOFTMAX_CE ? reinterpret_cast<const void *>(&rowblock_kernel<RbRuntimeShape<NL>, -1, 0>)
+                                          : reinterpret_cast<const void *>(&rowblock_kernel<RbRuntimeShape<NL>, -1, 1>);
+}
+
+void plan_rowblock(gnn_mlp *h) {
+    h->rb = false;
+    h->rb_fn = nullptr; h->rb_jit = nullptr; h->rb_static = 0;
+    if (!h->chain || h->dtype != GNN_DTYPE_F32 || h->env_rb_off) return;
+    RbParams &r = h->rbp;
+    r = RbParams{};
+    r.plan = make_rb_plan(h->dims.data(), h->L);
+    if (!r.plan.ok) return; // (the two-launch step then keeps middle4_kernel as its row-block kernel)
+    const int L = h->L, Lm = L - 1;
+    h->rb_lds_bytes = (size_t)r.plan.lds_floats * sizeof(float);
+    for (int l = 1; l < Lm; l++) { r.W[l] = h->W + h->w_off[l]; r.act[l] = h->act[l]; }
+    for (int l = 1; l <= Lm; l++) r.delta[l] = h->delta[l];
+    r.last_act = h->last_act;
+    r.inner_act = h->inner_act;
+    r.slabs = h->slabs; r.slab_rows = h->cap_rows;
+    const bool allow_static = !h->env_static_off && h->out_kind == GNN_OUT_SOFTMAX_CE;
+    if (allow_static && shape_matches<ShapeMnistA>(h)) { h->rb_fn = rb_fn_static<RbMnistA>(h->inner_act); h->rb_static = 1; }
+    else if (allow_static && shape_matches<ShapeMnistB>(h)) { h->rb_fn = rb_fn_static<RbMnistB>(h->inner_act); h->rb_static = 1; }
+    else {
+        switch (L) {
+        case 3: h->rb_fn = rb_fn_runtime<3>(h->out_kind); break;
+        case 4: h->rb_fn = rb_fn_runtime<4>(h->out_kind); break;
+        case 5: h->rb_fn = rb_fn_runtime<5>(h->out_kind); break;
+        case 6: h->rb_fn = rb_fn_runtime<6>(h->out_kind); break;
+        default: h->rb_fn = rb_fn_runtime<0>(h->out_kind); break;
+        }
+    }
+    if (hipFuncSetAttribute(h->rb_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rb_lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        h->rb_fn = nullptr;
+        return;
+    }
+    h->rb = true;
+}
+
 // Run-time instantiation of middle4_kernel for this net's shape (jit.h); silent no-op when the
 // net is already specialised, does not take the middle4 path, or hiprtc is unavailable.
 void try_specialize(gnn_mlp *h) {
@@ -107,6 +159,10 @@ void try_specialize(gnn_mlp *h) {
     h->mid4_jit[1] = sp->fn[1];
     h->mid4_jit[2] = sp->fn[2];
     h->specialization = 2;
+    if (h->rb && !h->rb_static) { // the training row-block kernel for this shape, from the same embedded sources
+        const jit::Specialised *rs = jit::get_rowblock(h->device, h->dims.data(), h->L, h->inner_act, h->out_kind, h->rb_lds_bytes);
+        if (rs) h->rb_jit = rs->fn[0];
+    }
 }
 
 // forward of the middle4 path; backward = also delta_1..delta_{L-1}
@@ -114,6 +170,33 @@ void try_specialize(gnn_mlp *h) {
 void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
                    bool want_loss, bool want_label, bool from_slabs) {
     if (!from_slabs) launch_fwd_first(h, a0, B);
+    if (from_slabs && h->rb) { // the two-launch step's training kernel (rowblock_kernel.h)
+        RbParams r = h->rbp;
+        r.slabs = h->slabs; r.slab_rows = h->cap_rows;
+        r.Y = y; r.ldy = h->ld[h->L - 1];
+        r.prob = want_prob ? h->prob : nullptr;
+        r.loss = want_loss ? h->lossv : nullptr;
+        r.label = want_label ? h->labels : nullptr;
+        r.B = B;
+        r.row_idx = h->cur_idx;
+        void *args[] = {&r};
+        const unsigned grid = (unsigned)(pad_up(B) / 4);
+        TimerClass &tc = h->timers[GNN_K_MIDDLE];
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (h->timing && tc.used < 8192) {
+            if (tc.used >= tc.start.size()) {
+                hipEvent_t a = nullptr, b = nullptr;
+                if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { tc.start.push_back(a); tc.stop.push_back(b); }
+            }
+            if (tc.used < tc.start.size()) { ev0 = tc.start[tc.used]; ev1 = tc.stop[tc.used]; tc.used++; }
+        }
+        hipError_t le;
+        if (h->rb_jit) le = hipExtModuleLaunchKernel(h->rb_jit, grid * (unsigned)RB_NT, 1, 1, RB_NT, 1, 1, h->rb_lds_bytes, h->stream, args, nullptr, ev0, ev1, 0);
+        else if (ev0) le = hipExtLaunchKernel(const_cast<void *>(h->rb_fn), dim3(grid), dim3(RB_NT), args, h->rb_lds_bytes, h->stream, ev0, ev1, 0);
+        else le = hipLaunchKernel(h->rb_fn, dim3(grid), dim3(RB_NT), args, h->rb_lds_bytes, h->stream);
+        if (le != hipSuccess && h->launch_error == hipSuccess) h->launch_error = le;
+        return;
+    }
     {
         Mid4Params m4 = h->mid4p;
         m4.slabs = h->slabs; m4.slab_rows = h->cap_rows; m4.n_slabs = h->n_slabs;

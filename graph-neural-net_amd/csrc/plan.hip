@@ -61,7 +61,7 @@ void plan_fused(gnn_mlp *h) {
     }
     // preferred: 4-row blocks with LDS-resident middle weights
     plan_mid4(h);
-    if (h->mid4) { h->fused = true; plan_chain(h); return; }
+    if (h->mid4) { h->fused = true; plan_chain(h); plan_rowblock(h); return; }
     // the middle weights do not fit LDS: per-layer tiled GEMMs for the middle, still bracketed by
     // the one-launch first layer and the one-launch gradient+update (a 16-row kernel that streamed
     // the middle weights from L2 was 15-40 % slower than this on every such shape and was removed)

@@ -1,0 +1,106 @@
+// rowblock_probe.hip -- development harness (not shipped): the training row-block kernel (rowblock_kernel.h) against
+// middle4_kernel<.., SLABS> on the 784-300-100-10 / B = 128 shapes with random slabs: outputs (tolerance: the K split of
+// the layer-2 product differs), HIP-event time per call, in-kernel phase stamps.
+#include "../graph-neural-net_amd/csrc/rowblock_kernel.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace gnn;
+using SS = StaticShape<784, 300, 100, 10>;
+using RS = RbStaticShape<784, 300, 100, 10>;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+int main(int argc, char **argv) {
+    const int L = 4, dims[4] = {784, 300, 100, 10};
+    const int B = argc > 1 ? atoi(argv[1]) : 128;
+    int ld[4]; for (int i = 0; i < L; i++) ld[i] = pad_up(dims[i]);
+    const int Bp = pad_up(B);
+    size_t woff[3], np = 0; for (int l = 0; l < 3; l++) { woff[l] = np; np += (size_t)ld[l] * ld[l + 1]; }
+    float *W, *Y, *slabs; unsigned long long *stamps;
+    CK(hipMalloc(&W, np * 4));
+    std::vector<float> hw(np, 0.f);
+    for (int l = 0; l < 3; l++) for (int i = 0; i < dims[l]; i++) for (int j = 0; j < dims[l + 1]; j++)
+        hw[woff[l] + (size_t)i * ld[l + 1] + j] = (rand() / (float)RAND_MAX - 0.5f) * 0.4f;
+    CK(hipMemcpy(W, hw.data(), np * 4, hipMemcpyHostToDevice));
+    std::vector<float> hy((size_t)Bp * ld[3], 0.f);
+    for (int b = 0; b < B; b++) hy[(size_t)b * ld[3] + rand() % 10] = 1.f;
+    CK(hipMalloc(&Y, hy.size() * 4)); CK(hipMemcpy(Y, hy.data(), hy.size() * 4, hipMemcpyHostToDevice));
+    const int ns = (ld[0] + 63) / 64;
+    std::vector<float> hsl((size_t)ns * Bp * ld[1], 0.f);
+    for (int s = 0; s < ns; s++) for (int b = 0; b < B; b++) for (int j = 0; j < dims[1]; j++) hsl[((size_t)s * Bp + b) * ld[1] + j] = (rand() / (float)RAND_MAX - 0.45f) * 0.3f;
+    CK(hipMalloc(&slabs, hsl.size() * 4)); CK(hipMemcpy(slabs, hsl.data(), hsl.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&stamps, 4096 * 16 * 8)); CK(hipMemset(stamps, 0, 4096 * 16 * 8));
+    // two sets of outputs
+    float *act[2][4], *delta[2][4];
+    for (int v = 0; v < 2; v++) for (int l = 1; l < L; l++) {
+        CK(hipMalloc(&act[v][l], (size_t)Bp * ld[l] * 4)); CK(hipMemset(act[v][l], 0xff, (size_t)Bp * ld[l] * 4));
+        CK(hipMalloc(&delta[v][l], (size_t)Bp * ld[l] * 4)); CK(hipMemset(delta[v][l], 0xff, (size_t)Bp * ld[l] * 4));
+    }
+    Mid4Params m4{}; m4.plan = make_mid4_plan(dims, L); const size_t lds4 = (size_t)m4.plan.lds_floats * 4;
+    for (int l = 1; l < 3; l++) { m4.W[l] = W + woff[l]; m4.act[l] = act[0][l]; }
+    for (int l = 1; l < L; l++) m4.delta[l] = delta[0][l];
+    m4.Y = Y; m4.ldy = ld[3]; m4.B = B; m4.inner_act = 0; m4.slabs = slabs; m4.slab_rows = Bp; m4.n_slabs = ns; m4.stamps = stamps;
+    RbParams rb{}; rb.plan = make_rb_plan(dims, L); const size_t ldsr = (size_t)rb.plan.lds_floats * 4;
+    printf("rowblock plan ok=%d LDS %zu bytes (middle4 %zu): ksf=%d units=%d upw=%d | gb=%d ksb=%d | lw1=%d lw2=%d\n", (int)rb.plan.ok, ldsr, lds4,
+           rb.plan.ksf[1], rb.plan.units[1], rb.plan.upw[1], rb.plan.gb[1], rb.plan.ksb[1], rb.plan.lw[1], rb.plan.lw[2]);
+    for (int l = 1; l < 3; l++) { rb.W[l] = W + woff[l]; rb.act[l] = act[1][l]; }
+    for (int l = 1; l < L; l++) rb.delta[l] = delta[1][l];
+    rb.Y = Y; rb.ldy = ld[3]; rb.B = B; rb.inner_act = 0; rb.slabs = slabs; rb.slab_rows = Bp; rb.stamps = stamps;
+    auto k_old = middle4_kernel<SS, 0, 0, true, false, true>;
+    auto k_new = rowblock_kernel<RS, 0, 0, false>;
+    auto k_new_rt = rowblock_kernel<RbRuntimeShape<4>, -1, 0, false>;
+    auto k_new_st = rowblock_kernel<RS, 0, 0, true>;
+    CK(hipFuncSetAttribute((const void *)k_old, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    CK(hipFuncSetAttribute((const void *)k_new, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+    CK(hipFuncSetAttribute((const void *)k_new_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+    CK(hipFuncSetAttribute((const void *)k_new_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    const dim3 grid((B + 3) / 4);
+    auto compare = [&](const char *name) {
+        CK(hipStreamSynchronize(s));
+        printf("%s:", name);
+        for (int which = 0; which < 2; which++) for (int l = 1; l < L; l++) {
+            if (which == 0 && l == 3) continue;
+            std::vector<float> a((size_t)Bp * ld[l]), b(a.size());
+            CK(hipMemcpy(a.data(), which ? delta[0][l] : act[0][l], a.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(b.data(), which ? delta[1][l] : act[1][l], b.size() * 4, hipMemcpyDeviceToHost));
+            double md = 0, mx = 0; int bad = 0;
+            for (size_t i = 0; i < a.size(); i++) { if (!(b[i] == b[i])) bad++; md = std::max(md, (double)fabsf(a[i] - b[i])); mx = std::max(mx, (double)fabsf(a[i])); }
+            printf(" %s%d max|d|=%.3g (scale %.3g, nan %d)", which ? "delta" : "act", l, md, mx, bad);
+        }
+        printf("\n");
+    };
+    hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4);
+    hipLaunchKernelGGL(k_new, grid, dim3(RB_NT), ldsr, s, rb);
+    compare("static vs middle4");
+    for (int l = 1; l < L; l++) { CK(hipMemset(act[1][l], 0xff, (size_t)Bp * ld[l] * 4)); CK(hipMemset(delta[1][l], 0xff, (size_t)Bp * ld[l] * 4)); }
+    hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, rb);
+    compare("runtime vs middle4");
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time_it = [&](const char *name, int n, auto fn) {
+        for (int i = 0; i < 20; i++) fn();
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < n; i++) fn();
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-44s %8.2f us per call\n", name, ms * 1000.f / n);
+    };
+    for (int rep = 0; rep < 2; rep++) {
+        time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
+        time_it("rowblock<static> (8 waves)", 500, [&]() { hipLaunchKernelGGL(k_new, grid, dim3(RB_NT), ldsr, s, rb); });
+        time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, rb); });
+    }
+    CK(hipMemsetAsync(stamps, 0, 4096 * 16 * 8, s));
+    hipLaunchKernelGGL(k_new_st, grid, dim3(RB_NT), ldsr, s, rb);
+    CK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> hs((size_t)32 * 16);
+    CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+    for (int w : {0, 7, 16, 31}) {
+        const unsigned long long *q = &hs[w * 16];
+        printf("rowblock wg%-2d: slabs->A1 %llu | L2 product %llu | L2 reduce %llu | row tail %llu | backward %llu | total %llu cycles\n", w,
+               q[1] - q[0], q[2] - q[1], q[3] - q[2], q[12] - q[3], q[14] - q[12], q[14] - q[0]);
+    }
+    return 0;
+}
