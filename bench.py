@@ -70,6 +70,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="same as --dp-mode eager")
     ap.add_argument("--dp-path", action="store_true",
                     help="run the data-parallel code path (compute -> all_reduce -> update) even at N=1")
+    ap.add_argument("--dp-impl", choices=["ranks", "library"], default="ranks",
+                    help="N > 1: one process per GPU over torch.distributed/RCCL (default), or ONE process whose handle owns the N "
+                         "devices (gnn_mlp_dp_*: what a single-threaded JVM caller uses)")
+    ap.add_argument("--dp-reducer", choices=["rccl", "direct", "direct_rs"], default="rccl",
+                    help="--dp-impl library: RCCL all-reduce, or the peer-memory reducers (all-read-all / reduce-scatter + gather)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control flow on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -260,6 +265,50 @@ def cpu_baseline(seconds=12.0):
     return {"value": round(steps * BATCH / dt, 1), "unit": "samples/s", "cores": 1, "kind": "port",
             "sample": "%d gradientSteps of batch %d on 784-300-100-10 (fp64, per-sample loop order of "
                       "SCE:297-346; C restatement, not a JVM run)" % (steps, BATCH)}
+
+
+def library_worker(args):
+    """--dp-impl library: ONE process, one handle over N devices (include/gnn_mlp.h, gnn_mlp_dp_*).  Same workload and the
+    same JSON line as the one-process-per-GPU form: 128 rows per device, global batch 128 N, one sum of the flat gradient
+    per step inside the library.  --share-gpu puts every replica on device 0 (peer-memory reducers only): a rehearsal of
+    the control flow on a one-GPU box, not a scaling number."""
+    import numpy as np
+    import torch
+    import gnn_amd
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    n = args.gpus
+    if not args.share_gpu and torch.cuda.device_count() < n:
+        sys.exit("bench.py --dp-impl library: %d devices asked, %d visible" % (n, torch.cuda.device_count()))
+    reducer = {"rccl": gnn_amd.REDUCE_RCCL, "direct": gnn_amd.REDUCE_DIRECT, "direct_rs": gnn_amd.REDUCE_DIRECT_RS}[args.dp_reducer]
+    K, W = args.steps, args.warmup
+    bf16 = args.dtype == "bf16"
+    Bg = BATCH * n
+    X, Y = synthetic(Bg * N_BATCHES, 1000)
+    net = gnn_amd.DataParallelNeuralNet(DIMS, devices=[0] * n if args.share_gpu else list(range(n)), max_batch=Bg, reducer=reducer,
+                                        dtype=gnn_amd.DTYPE_BF16 if bf16 else gnn_amd.DTYPE_F32)
+    net.upload_dataset(X, Y)
+    net.train_range(0, Bg, W, STEP, MOMENTUM)
+    net.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    net.train_range((W % N_BATCHES) * Bg, Bg, K, STEP, MOMENTUM)
+    net.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    line = {
+        "metric": "training samples/sec, 784-300-100-10 MLP batch 128",
+        "value": round(K * Bg / dt, 1), "unit": "samples/s", "n_gpus": n, "steps": K, "warmup": W,
+        "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "784-300-100-10 SoftmaxCrossEntropyNeuralNet gradientStep, %s, batch 128 per GPU (BASELINE configs[%d])"
+                               % (("bf16 GEMM operands / f32 accumulate and masters", 2) if bf16 else ("fp32", 1)),
+                   "global_batch": Bg, "parallelism": "dp%d" % n, "dp_impl": "library: one process, one handle over %d devices" % n,
+                   "backend": args.dp_reducer, "world_size": n, "devices_shared": bool(args.share_gpu),
+                   "dp_replicas_identical": net.replicas_identical(), "step": STEP, "momentum": MOMENTUM, "inner_activation": "leaky_relu"},
+        "roofline": None, "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
 
 
 def supervise_own_rank(args, argv):
@@ -596,6 +645,9 @@ def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
     world_env = os.environ.get("WORLD_SIZE")
+    if args.dp_impl == "library" and world_env is None:
+        library_worker(args)
+        return
     if world_env is None and args.gpus > 1:
         sys.exit(launch(args, argv))       # nothing GPU-related has been imported in this process
     if world_env is not None and int(world_env) != args.gpus:

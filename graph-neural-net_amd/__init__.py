@@ -11,7 +11,7 @@ from . import build as build_lib  # noqa: F401
 from ._capi import GnnError, load as load_library, lib_path  # noqa: F401
 from .neural_net import (  # noqa: F401
     ACT_IDENTITY, ACT_LEAKY_RELU, ACT_RELU, ACT_SIGMOID, ACT_TANH, DTYPE_BF16, DTYPE_F32,
-    LOSS_HALF_SQUARED, OUT_ACT_LOSS, OUT_SOFTMAX_CE, REDUCE_DIRECT, REDUCE_RCCL, DataParallelNeuralNet, GeneralNeuralNet,
+    LOSS_HALF_SQUARED, OUT_ACT_LOSS, OUT_SOFTMAX_CE, REDUCE_DIRECT, REDUCE_DIRECT_RS, REDUCE_RCCL, DataParallelNeuralNet, GeneralNeuralNet,
     NeuralNet, SoftmaxCrossEntropyNeuralNet)
 from .trainer import (  # noqa: F401
     NeuralNetTrainer, Sampler, accuracy, log_test, read_idx_images, read_idx_labels, train_log_row)

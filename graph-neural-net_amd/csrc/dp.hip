@@ -3,6 +3,7 @@
 #include "handle.h"
 #include "dp_handle.h"
 
+#include <algorithm>
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
@@ -67,8 +68,11 @@ struct gnn_mlp_dp {
     std::vector<gnn_mlp *> rep;
     std::vector<int> dev;
     std::vector<void *> comm;                     // GNN_REDUCE_RCCL
-    std::vector<float *> gbuf[2];                 // GNN_REDUCE_DIRECT: gradient buffers by step parity
+    std::vector<float *> gbuf[2];                 // GNN_REDUCE_DIRECT / _RS: gradient buffers by step parity
     std::vector<hipEvent_t> grad_done[2], red_done[2];
+    std::vector<float *> red;                     // GNN_REDUCE_DIRECT_RS: each replica's reduced slice (indexed like the gradient)
+    std::vector<hipEvent_t> scat_done;
+    int64_t slice = 0;                            // floats per owner, a multiple of 16
     int64_t steps = 0;
 };
 
@@ -105,29 +109,69 @@ int dp_reduce_and_update(gnn_mlp_dp *d, int B_global, double step, double moment
         for (int r = 0; r < n; r++) TRY(gnn_mlp_apply_update(d->rep[r], B_global, step, momentum));
         return GNN_OK;
     }
-    // direct: events order the devices, one kernel per replica reads every partial gradient
+    // direct: events order the devices; the sum, the update and (two-launch nets with the next batch known) the next
+    // step's first layer are ONE kernel per replica, reading every partial gradient through peer pointers
+    static_assert(TS_MAX_PEERS == DP_MAX_REPLICAS, "tile_step_kernel's peer table and the handle's replica limit");
     const int par = (int)(d->steps & 1);
+    const float sob = (float)(step / (double)B_global), mom = (float)momentum;
     for (int r = 0; r < n; r++) {
         gnn_mlp *h = d->rep[r];
         HIP_TRY(hipSetDevice(d->dev[r]));
         HIP_TRY(hipEventRecord(d->grad_done[par][r], h->stream));
     }
+    if (d->reducer == GNN_REDUCE_DIRECT_RS) { // phase 1: replica r reduces slice r
+        for (int r = 0; r < n; r++) {
+            gnn_mlp *h = d->rep[r];
+            HIP_TRY(hipSetDevice(d->dev[r]));
+            for (int j = 0; j < n; j++)
+                if (j != r) HIP_TRY(hipStreamWaitEvent(h->stream, d->grad_done[par][j], 0));
+            DirectScatterParams p{};
+            for (int j = 0; j < n; j++) p.G[j] = reinterpret_cast<const float4 *>(d->gbuf[par][j]);
+            p.n = n;
+            p.red = reinterpret_cast<float4 *>(d->red[r]);
+            p.lo4 = std::min<int64_t>((int64_t)r * d->slice, h->n_pad) / 4;
+            p.hi4 = std::min<int64_t>((int64_t)(r + 1) * d->slice, h->n_pad) / 4;
+            if (p.hi4 > p.lo4) launch_timed(h, -1, direct_reduce_scatter_kernel, dim3(grid_for(p.hi4 - p.lo4)), dim3(256), 0, p);
+            HIP_TRY(hipEventRecord(d->scat_done[r], h->stream));
+        }
+    }
     for (int r = 0; r < n; r++) {
         gnn_mlp *h = d->rep[r];
         HIP_TRY(hipSetDevice(d->dev[r]));
+        const bool rs = d->reducer == GNN_REDUCE_DIRECT_RS;
         for (int j = 0; j < n; j++)
-            if (j != r) HIP_TRY(hipStreamWaitEvent(h->stream, d->grad_done[par][j], 0));
-        DirectReduceParams p{};
-        for (int j = 0; j < n; j++) p.G[j] = reinterpret_cast<const float4 *>(d->gbuf[par][j]);
-        p.n = n;
-        p.W = reinterpret_cast<float4 *>(h->W); p.V = reinterpret_cast<float4 *>(h->V);
-        p.Wb = reinterpret_cast<sgd_bf16x4 *>(h->Wb);
-        p.n4 = h->n_pad / 4;
-        p.step_over_b = (float)(step / (double)B_global); p.momentum = (float)momentum;
-        launch_timed(h, GNN_K_UPDATE, direct_reduce_update_kernel, dim3(grid_for(p.n4)), dim3(256), 0, p);
+            if (j != r) HIP_TRY(hipStreamWaitEvent(h->stream, rs ? d->scat_done[j] : d->grad_done[par][j], 0));
+        NextBatch nb{};
+        if (h->chain && take_next(h, &nb)) {
+            // by weight tiles: each tile's sum (or gather) -> update -> the next batch's first-layer slab, one launch
+            PeerGradients pg{};
+            for (int j = 0; j < n; j++) pg.G[j] = rs ? d->red[j] : d->gbuf[par][j];
+            pg.n = n; pg.slice = (unsigned)d->slice;
+            launch_tile_step(h, rs ? 4 : 3, 2, &nb, nullptr, PAD, sob, mom, false, &pg);
+            slabs_now_hold(h, nb, nb.idx != nullptr);
+        } else if (rs) {
+            DirectGatherParams p{};
+            for (int j = 0; j < n; j++) p.red[j] = reinterpret_cast<const float4 *>(d->red[j]);
+            p.n = n; p.slice4 = d->slice / 4;
+            p.W = reinterpret_cast<float4 *>(h->W); p.V = reinterpret_cast<float4 *>(h->V);
+            p.Wb = reinterpret_cast<sgd_bf16x4 *>(h->Wb);
+            p.n4 = h->n_pad / 4;
+            p.step_over_b = sob; p.momentum = mom;
+            launch_timed(h, GNN_K_UPDATE, direct_gather_update_kernel, dim3(grid_for(p.n4)), dim3(256), 0, p);
+            h->slab_valid = false; h->have_next = false;
+        } else {
+            DirectReduceParams p{};
+            for (int j = 0; j < n; j++) p.G[j] = reinterpret_cast<const float4 *>(d->gbuf[par][j]);
+            p.n = n;
+            p.W = reinterpret_cast<float4 *>(h->W); p.V = reinterpret_cast<float4 *>(h->V);
+            p.Wb = reinterpret_cast<sgd_bf16x4 *>(h->Wb);
+            p.n4 = h->n_pad / 4;
+            p.step_over_b = sob; p.momentum = mom;
+            launch_timed(h, GNN_K_UPDATE, direct_reduce_update_kernel, dim3(grid_for(p.n4)), dim3(256), 0, p);
+            h->slab_valid = false; h->have_next = false;
+        }
         HIP_TRY(hipEventRecord(d->red_done[par][r], h->stream));
         h->time++;
-        h->slab_valid = false; h->have_next = false;
         TRY_LAUNCHES(h);
     }
     return GNN_OK;
@@ -155,7 +199,7 @@ int gnn_mlp_dp_create(const int32_t *dims, int n_dims, int out_kind, int inner_a
     if (!out) return fail(GNN_ERR_BAD_ARG, "out is null");
     *out = nullptr;
     if (!devices || n_dev < 1 || n_dev > DP_MAX_REPLICAS) return fail(GNN_ERR_BAD_ARG, "n_dev must be 1..16");
-    if (reducer != GNN_REDUCE_RCCL && reducer != GNN_REDUCE_DIRECT) return fail(GNN_ERR_BAD_ARG, "bad reducer");
+    if (reducer != GNN_REDUCE_RCCL && reducer != GNN_REDUCE_DIRECT && reducer != GNN_REDUCE_DIRECT_RS) return fail(GNN_ERR_BAD_ARG, "bad reducer");
     if (max_batch <= 0) return fail(GNN_ERR_BAD_ARG, "max_batch must be positive");
     if (reducer == GNN_REDUCE_RCCL) {
         for (int i = 0; i < n_dev; i++)
@@ -202,8 +246,21 @@ int gnn_mlp_dp_create(const int32_t *dims, int n_dims, int out_kind, int inner_a
                     return cleanup(fail(GNN_ERR_HIP, "hipEventCreate"));
                 d->grad_done[par].push_back(a); d->red_done[par].push_back(b);
             }
+            if (reducer == GNN_REDUCE_DIRECT_RS) {
+                float *g = nullptr;
+                const int rc = dev_alloc(&g, (size_t)d->rep[r]->n_pad, d->rep[r]->stream);
+                if (rc != GNN_OK) return cleanup(rc);
+                d->red.push_back(g);
+                hipEvent_t e = nullptr;
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return cleanup(fail(GNN_ERR_HIP, "hipEventCreate"));
+                d->scat_done.push_back(e);
+            }
             if (hipStreamSynchronize(d->rep[r]->stream) != hipSuccess) return cleanup(fail(GNN_ERR_HIP, "hipStreamSynchronize"));
         }
+    }
+    {   // floats per owner: the flat (padded) buffer cut into n_dev pieces on 16-float boundaries
+        const int64_t np = d->rep[0]->n_pad;
+        d->slice = ((np + n_dev - 1) / n_dev + 15) / 16 * 16;
     }
     *out = d;
     return GNN_OK;
@@ -225,6 +282,8 @@ int gnn_mlp_dp_destroy(gnn_mlp_dp_t *d) { return guarded([&]() -> int {
         for (hipEvent_t e : d->grad_done[par]) (void)hipEventDestroy(e);
         for (hipEvent_t e : d->red_done[par]) (void)hipEventDestroy(e);
     }
+    for (size_t r = 0; r < d->red.size(); r++) { (void)hipSetDevice(d->dev[r]); (void)hipFree(d->red[r]); }
+    for (hipEvent_t e : d->scat_done) (void)hipEventDestroy(e);
     for (gnn_mlp *h : d->rep) (void)gnn_mlp_destroy(h);
     delete d;
     return GNN_OK;
@@ -252,7 +311,7 @@ int gnn_mlp_dp_gradient_step(gnn_mlp_dp_t *d, const double *X, const double *Y, 
         dp_shard(B, r, d->n, &lo, &hi);
         gnn_mlp *h = d->rep[r];
         TRY(check_handle(h));
-        if (d->reducer == GNN_REDUCE_DIRECT) TRY(dp_direct_begin(d, r));
+        if (d->reducer != GNN_REDUCE_RCCL) TRY(dp_direct_begin(d, r));
         if (hi > lo) TRY(gnn_mlp_compute_gradient(h, X + (size_t)lo * d0, Y + (size_t)lo * dl, hi - lo));
         else HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * (size_t)h->n_pad, h->stream)); // no rows: a zero partial gradient
     }
@@ -273,8 +332,8 @@ static int dp_step_range(gnn_mlp_dp *d, int64_t first, int B, double step, doubl
         dp_shard(B, r, d->n, &lo, &hi);
         gnn_mlp *h = d->rep[r];
         TRY(check_handle(h));
-        if (d->reducer == GNN_REDUCE_DIRECT) TRY(dp_direct_begin(d, r));
-        else if (next_first >= 0 && hi > lo) TRY(gnn_mlp_hint_next_range(h, next_first + lo, hi - lo)); // the update kernel then starts the next step
+        if (d->reducer != GNN_REDUCE_RCCL) TRY(dp_direct_begin(d, r));
+        if (next_first >= 0 && hi > lo) TRY(gnn_mlp_hint_next_range(h, next_first + lo, hi - lo)); // the update kernel then starts the next step
         if (hi > lo) TRY(gnn_mlp_compute_gradient_range(h, first + lo, hi - lo));
         else HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * (size_t)h->n_pad, h->stream));
     }

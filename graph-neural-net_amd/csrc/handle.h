@@ -259,13 +259,14 @@ void to_bf16(gnn_mlp *h, const float *src, __bf16 *dst, size_t n);
 
 // ---- launch_small.hip: the row-block kernel and the tile-owner kernel ----------------------------
 struct NextBatch { const float *a0; const int32_t *idx; int B; };
+struct PeerGradients { const float *G[TS_MAX_PEERS]; int n; unsigned slice; }; // gsrc 3 / 4 of launch_tile_step (dp.hip)
 void plan_mid4(gnn_mlp *h);
 void plan_rowblock(gnn_mlp *h); // (after plan_chain: the kernel exists for the two-launch step only)
 void try_specialize(gnn_mlp *h);
 void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
                    bool want_loss, bool want_label, bool from_slabs = false);
 void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, const float *a0, int B, float step_over_b, float momentum,
-                      bool staged = false);
+                      bool staged = false, const PeerGradients *peers = nullptr);
 
 // ---- launch_misc.hip: encodings, gathers, the flat update ---------------------------------------
 void launch_convert_rows(gnn_mlp *h, const double *src, int d, float *dst, int ld, int64_t rows, int64_t rows_pad, int act, int apply_act);

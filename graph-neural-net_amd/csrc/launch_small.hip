@@ -238,8 +238,12 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
 // gsrc / gdst / fwd as in tile_step_kernel.h; fwd_only_layer0: the grid covers layer 0's tiles only
 // staged: the current batch's rows come from the contiguous copy xstage[xstage_cur] instead of (a0, cur_idx)
 void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, const float *a0, int B, float step_over_b, float momentum,
-                      bool staged) {
+                      bool staged, const PeerGradients *peers) {
     TileStepParams t = h->tsp;
+    if (peers) {
+        for (int r = 0; r < peers->n; r++) t.Gpeer[r] = peers->G[r];
+        t.n_peer = peers->n; t.slice = peers->slice; t.Gself = h->G;
+    }
     t.layer[0].A = staged ? h->xstage[h->xstage_cur] : a0;
     for (int l = 0; l < t.n_layers; l++) t.layer[l].G = h->G + h->w_off[l];
     t.K = pad_up(B); t.k_true = B;
@@ -252,7 +256,7 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
     const bool fwd_only = gsrc == 0;
     const dim3 grid(fwd_only ? h->ts_tiles0 : h->ts_tiles), block(TS_THREADS);
     if (fwd_only) t.n_layers = 1;
-    const int cls = fwd_only ? GNN_K_FWD_GEMM0 : gsrc == 2 ? GNN_K_UPDATE : GNN_K_GRAD_GEMM0;
+    const int cls = fwd_only ? GNN_K_FWD_GEMM0 : gsrc >= 2 ? GNN_K_UPDATE : GNN_K_GRAD_GEMM0;
     if (h->dtype == GNN_DTYPE_BF16) {
         if (staged) t.Ab[0] = h->xstage_b[h->xstage_cur];
         else if (a0) t.Ab[0] = a0_bf16(h, a0);
@@ -262,7 +266,11 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
         else if (gsrc == 1 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_bf16_kernel<1, 2, false>, grid, block, 0, t);
         else if (gsrc == 1 && gdst == 2 && fwd) launch_timed(h, cls, tile_step_bf16_kernel<1, 2, true>, grid, block, 0, t);
         else if (gsrc == 2 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_bf16_kernel<2, 2, false>, grid, block, 0, t);
-        else launch_timed(h, cls, tile_step_bf16_kernel<2, 2, true>, grid, block, 0, t);
+        else if (gsrc == 2) launch_timed(h, cls, tile_step_bf16_kernel<2, 2, true>, grid, block, 0, t);
+        else if (gsrc == 3 && !fwd) launch_timed(h, cls, tile_step_bf16_kernel<3, 2, false>, grid, block, 0, t);
+        else if (gsrc == 3) launch_timed(h, cls, tile_step_bf16_kernel<3, 2, true>, grid, block, 0, t);
+        else if (!fwd) launch_timed(h, cls, tile_step_bf16_kernel<4, 2, false>, grid, block, 0, t);
+        else launch_timed(h, cls, tile_step_bf16_kernel<4, 2, true>, grid, block, 0, t);
         return;
     }
     if (fwd_only) launch_timed(h, cls, tile_step_kernel<0, 0, true>, grid, block, 0, t);
@@ -270,7 +278,11 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
     else if (gsrc == 1 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_kernel<1, 2, false>, grid, block, 0, t);
     else if (gsrc == 1 && gdst == 2 && fwd) launch_timed(h, cls, tile_step_kernel<1, 2, true>, grid, block, 0, t);
     else if (gsrc == 2 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_kernel<2, 2, false>, grid, block, 0, t);
-    else launch_timed(h, cls, tile_step_kernel<2, 2, true>, grid, block, 0, t);
+    else if (gsrc == 2) launch_timed(h, cls, tile_step_kernel<2, 2, true>, grid, block, 0, t);
+    else if (gsrc == 3 && !fwd) launch_timed(h, cls, tile_step_kernel<3, 2, false>, grid, block, 0, t);
+    else if (gsrc == 3) launch_timed(h, cls, tile_step_kernel<3, 2, true>, grid, block, 0, t);
+    else if (!fwd) launch_timed(h, cls, tile_step_kernel<4, 2, false>, grid, block, 0, t);
+    else launch_timed(h, cls, tile_step_kernel<4, 2, true>, grid, block, 0, t);
 }
 
 } // namespace host

@@ -143,11 +143,14 @@ template <int NL> struct RbRuntimeShape {
         if (STAMP && threadIdx.x == 0) p.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();   \
     } while (0)
 
-// x + (x of the lane 32 away): both halves of the wave end up with the sum
+// x + (x of the lane 32 away): both halves of the wave end up with the sum.
+// (The two results are copied to scalars before they are reinterpreted: `__builtin_bit_cast(float, r[1])` on the builtin's
+//  vector result read element 0 twice with hipcc 7.2 -- every sum came out as 2 x one half.)
 __device__ __forceinline__ float rb_sum32(float x) {
     const unsigned u = __builtin_bit_cast(unsigned, x);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    const unsigned lo = r[0], hi = r[1];
+    return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
 }
 
 // NL > 0: layer count fixed at compile time; IS_STATIC: `m` is a compile-time constant (every extent folds)
@@ -185,7 +188,13 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
             if (i < m.ns) zs[i] = m4_load16(p.slabs, zoff + (a1_on ? (unsigned)i * sstride : 0u));
         }
     }
-    __builtin_amdgcn_sched_barrier(0); // issue order = the order the data is needed in: loads return in order
+    // Issue order = the order the data is needed in.  Within a wave loads return in order; ACROSS the waves the memory
+    // pipeline serves requests roughly as they arrive, so every wave's slab requests are put in front of any wave's weight
+    // requests: a bare barrier (nothing is waited for) between the two groups.  Without it A_1 was ready only when the
+    // weights had landed too (5 500 cycles after the start instead of ~2 500: tools/rowblock_probe).
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     // (b) this wave's K slice of the first register product (W_1 -> layer 2): 8-row units, 16 B per lane
     //     lane (hq, lq): rows 8u + 4hq + 0..3 of the unit, columns 128 cslice + 4 lq .. +3
     const int hq = lane >> 5, lq = lane & 31;
@@ -274,12 +283,11 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
             }
         };
         if (l == 1 && UPW1 > 0) {
+            // a unit's rows go to the LDS image right behind its MFMAs: the writes (13 cycles of the LDS store path each) run
+            // under the matrix pipe's 128 cycles per unit and under the wait for the next unit's loads
 #pragma unroll
             for (int uu = 0; uu < UPW1; uu++)
-                if (uu < nu) unit(u0 + uu, w1[uu]);
-#pragma unroll
-            for (int uu = 0; uu < UPW1; uu++)
-                if (uu < nu) to_image(u0 + uu, w1[uu]);
+                if (uu < nu) { unit(u0 + uu, w1[uu]); to_image(u0 + uu, w1[uu]); }
         } else {
             // later layers (nets of five and more layers): the slice is loaded here, RB_MAXU units at a time
             for (int ub = 0; ub < nu; ub += RB_MAXU) {

@@ -10,6 +10,10 @@
 //
 //   GSRC = 1  G = A_l^T . delta_{l+1} over the batch rows            (MFMA, K = batch)
 //   GSRC = 2  G = the tile of the all-reduced gradient buffer        (data parallel)
+//   GSRC = 3  G = the rank-ordered SUM of the tile in every replica's gradient buffer (data parallel inside the library,
+//             GNN_REDUCE_DIRECT: peer pointers -- the reduction, the update and the next step's first layer in ONE launch)
+//   GSRC = 4  G = the tile of the REDUCED gradient, each 16-float piece read from the replica that owns its slice
+//             (GNN_REDUCE_DIRECT_RS: a reduce-scatter kernel ran before; this launch is the all-gather + update + first layer)
 //   GDST = 1  stores G                                               (data parallel: the all-reduce follows)
 //   GDST = 2  adj = (step*G)/B + momentum*prev ; W -= adj ; prev = adj
 //   FWD       layer 0 only: Zp[b][n] = sum over the tile's 64 input neurons of A_0'[b][m] . W_0[m][n]
@@ -38,6 +42,7 @@ namespace gnn {
 
 constexpr int TS_TM = 64, TS_TN = 16, TS_THREADS = 512, TS_KC = 128;
 constexpr int TS_MAX_SLABS = 16; // middle4_kernel keeps one float4 per slab in registers
+constexpr int TS_MAX_PEERS = 16; // replicas of one data-parallel handle (dp_handle.h: DP_MAX_REPLICAS)
 
 struct TileStepParams {
     GradLayer layer[MAX_LAYERS]; // tiling in 64 x 16 tiles; block_begin per layer
@@ -59,7 +64,38 @@ struct TileStepParams {
     // contiguous copy [next_K][ldan] (f32 or bf16 by kernel), which the NEXT step's gradient product then reads in place of
     // the index-gathered rows -- no dependent index load at the start of that kernel.  Null = no copy.
     float *stage_out; __bf16 *stage_out_b;
+    // GSRC = 3 / 4: every replica's gradient buffer (3: partial gradients, 4: reduced slices), rank order; Gself = the base
+    // of THIS replica's bound gradient buffer (layer[l].G - Gself is the layer's offset in every peer's buffer); slice =
+    // floats per owner (a multiple of 16), GSRC = 4 only
+    const float *Gpeer[TS_MAX_PEERS]; int n_peer; const float *Gself; unsigned slice;
 };
+
+// the gradient tile's 16 B of this lane when it does not come from this launch's own product
+template <int GSRC> __device__ __forceinline__ float4 ts_gradient_in(const TileStepParams &p, const GradLayer &L, size_t e_off, bool e_ok) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!e_ok) return g;
+    if (GSRC == 2) {
+        g = *reinterpret_cast<const float4 *>(L.G + e_off);
+    } else if (GSRC == 3) {
+        const size_t off = (size_t)(L.G - p.Gself) + e_off;
+        g = *reinterpret_cast<const float4 *>(p.Gpeer[0] + off);
+#pragma unroll
+        for (int r = 1; r < TS_MAX_PEERS; r++) {
+            if (r < p.n_peer) { // (block-uniform; rank order: the same bits on every replica)
+                const float4 o = *reinterpret_cast<const float4 *>(p.Gpeer[r] + off);
+                g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+            }
+        }
+    } else if (GSRC == 4) {
+        const size_t off = (size_t)(L.G - p.Gself) + e_off;
+        const unsigned owner = (unsigned)off / p.slice; // (a 16-float row piece never straddles two owners)
+        const float *src = p.Gpeer[0];
+#pragma unroll
+        for (int r = 1; r < TS_MAX_PEERS; r++) src = (owner == (unsigned)r) ? p.Gpeer[r] : src;
+        g = *reinterpret_cast<const float4 *>(src + off);
+    }
+    return g;
+}
 
 #define GNN_TS_STAMP(i)                                                                                  \
     do {                                                                                                 \
@@ -137,8 +173,8 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     if (e_ok) {
         if (GDST == 2 || FWD) w_old = *reinterpret_cast<const float4 *>(L.W + e_off);
         if (GDST == 2) v_old = *reinterpret_cast<const float4 *>(L.V + e_off);
-        if (GSRC == 2) g_in = *reinterpret_cast<const float4 *>(L.G + e_off);
     }
+    if (GSRC >= 2) g_in = ts_gradient_in<GSRC>(p, L, e_off, e_ok);
     const bool next_plain = interior && fwd && !p.next_idx && p.next_rows >= TS_KC && (unsigned long long)TS_KC * (unsigned)p.ldan < 0xffffffffull; // the first chunk of the next batch: all rows live, in place
     // the next batch's rows, already in MFMA fragment form: wave -> 16 batch rows of a 128-row chunk, lane
     // (fr, fq) -> row fr, inputs 16c + 4fq .. +3 of the tile (c = 0..3).  Straight to registers: A_0' is
@@ -350,8 +386,8 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
     if (e_ok) {
         if (GDST == 2 || FWD) w_old = *reinterpret_cast<const float4 *>(L.W + e_off);
         if (GDST == 2) v_old = *reinterpret_cast<const float4 *>(L.V + e_off);
-        if (GSRC == 2) g_in = *reinterpret_cast<const float4 *>(L.G + e_off);
     }
+    if (GSRC >= 2) g_in = ts_gradient_in<GSRC>(p, L, e_off, e_ok);
     // next batch: lane (fr, fg) of wave w -> row 16w + fr; per 32-wide k block the inputs 4fg..4fg+3 and 16+4fg..+3
     s16x4 vn[2][2];
     int next_row0 = wave * 16 + fr; // (as in tile_step_kernel: the index of a sampled next batch's row is fetched ahead)

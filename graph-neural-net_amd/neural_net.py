@@ -325,7 +325,7 @@ class GeneralNeuralNet(NeuralNet):
                          device=device, max_batch=max_batch)
 
 
-REDUCE_RCCL, REDUCE_DIRECT = 0, 1
+REDUCE_RCCL, REDUCE_DIRECT, REDUCE_DIRECT_RS = 0, 1, 2
 
 
 class _ReplicaView(NeuralNet):

@@ -233,7 +233,7 @@ int gnn_mlp_recover_stream(gnn_mlp_t *h);
  * Everything that is per net (propagate, loss, argmax, get/set of weights, checkpoint) goes through a
  * replica's own handle, gnn_mlp_dp_replica(h, r, &net) -- borrowed, never destroyed by the caller. */
 typedef struct gnn_mlp_dp gnn_mlp_dp_t;
-typedef enum { GNN_REDUCE_RCCL = 0, GNN_REDUCE_DIRECT = 1 } gnn_reducer;
+typedef enum { GNN_REDUCE_RCCL = 0, GNN_REDUCE_DIRECT = 1, GNN_REDUCE_DIRECT_RS = 2 } gnn_reducer;
 int gnn_mlp_dp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act, int last_act, int loss,
                       int64_t seed, int dtype, const int32_t *devices, int n_dev, int max_batch, int reducer,
                       gnn_mlp_dp_t **out);

@@ -52,6 +52,13 @@ def test_bench_line_single_process():
     assert line["roofline"]["traffic"] is None or isinstance(line["roofline"]["traffic"], int)
     assert 0 < line["roofline"]["gemm_784x300_mfma_frac"] < 1
     assert 0 < line["host_batch_samples_per_s"] < line["value"]   # PCIe-inclusive NeuralNet.gradientStep(double[]) rate
+    # the same K steps between two events on the launch stream: within a few per cent of the wall clock
+    assert 0.5 * line["ms_per_step"] <= line["ms_per_step_events"] <= 1.05 * line["ms_per_step"]
+    oc = line["other_configs"]                   # short same-run timings of configs[0], [3], [4]
+    for name in ("configs[0] f32", "configs[3] f32", "configs[3] bf16", "configs[4] f32 eager", "configs[4] f32 hipGraph", "configs[4] bf16"):
+        assert "error" not in oc[name], oc[name]
+        assert oc[name]["samples_per_s"] > 0 and oc[name]["us_per_step_events"] > 0
+    assert oc["configs[4] f32 hipGraph"]["hipgraph"] is True
 
 
 def test_bench_line_bf16():
@@ -105,3 +112,16 @@ def test_bench_capture_failure_under_external_launcher():
     check(line)
     assert "hipGraph capture failed" in out.stderr and "rank supervisor" in out.stderr
     assert line["config"]["dp_mode"] == "eager"
+
+
+@pytest.mark.parametrize("reducer", ["direct", "direct_rs"])
+def test_bench_library_data_parallel_rehearsal(reducer):
+    """--dp-impl library: ONE process, one handle over N replicas (gnn_mlp_dp_train_range); on this box the replicas share
+    device 0, which the peer-memory reducers accept.  Same driver keys; replicas identical."""
+    line = run_bench("--gpus", "4", "--dp-impl", "library", "--dp-reducer", reducer, "--share-gpu")
+    for k in KEYS:
+        if k != "host_batch_samples_per_s":
+            assert k in line, k
+    assert line["n_gpus"] == 4 and line["config"]["global_batch"] == 512 and line["config"]["world_size"] == 4
+    assert line["config"]["dp_replicas_identical"] is True and line["config"]["backend"] == reducer
+    assert abs(line["value"] - 512 * 128 / (line["ms_per_step"] * 1e-3 * 128)) <= 0.01 * line["value"]

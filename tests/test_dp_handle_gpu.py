@@ -42,11 +42,15 @@ def test_rccl_world_of_one(gnn):
         gnn.DataParallelNeuralNet(DIMS, devices=[0, 0], max_batch=B, reducer=gnn.REDUCE_RCCL)
 
 
+@pytest.mark.parametrize("rs", [False, True], ids=["direct", "direct_rs"])
 @pytest.mark.parametrize("n_rep,B", [(2, 128), (3, 100), (4, 64)])
-def test_direct_reducer_replicas_sharing_one_device(gnn, n_rep, B):
+def test_direct_reducer_replicas_sharing_one_device(gnn, n_rep, B, rs):
+    """Both peer-memory reducers: DIRECT (every replica sums all partial gradients) and DIRECT_RS (reduce-scatter, then
+    gather while updating).  train_range names each step's successor, so the reduction runs inside the tile-owner kernel
+    (tile_step_kernel<GSRC = 3 / 4>); the last step, with no successor, takes the flat kernels."""
     steps = 7
     X, Y = data(B * 3, seed=n_rep)
-    net = gnn.DataParallelNeuralNet(DIMS, devices=[0] * n_rep, max_batch=B, reducer=gnn.REDUCE_DIRECT)
+    net = gnn.DataParallelNeuralNet(DIMS, devices=[0] * n_rep, max_batch=B, reducer=gnn.REDUCE_DIRECT_RS if rs else gnn.REDUCE_DIRECT)
     assert len(net.replicas) == n_rep
     net.upload_dataset(X, Y)
     net.train_range(0, B, steps, 0.0125, 0.9)
@@ -120,3 +124,25 @@ def test_config3_eight_way_global_batch_1024_bf16(gnn):
         net2.gradientStep(X[s * Bg:(s + 1) * Bg], 0.0125, 0.9, False, expected=Y[s * Bg:(s + 1) * Bg])
     assert net2.replicas_identical()
     assert np.array_equal(net2.get_weights(), net.get_weights())
+
+
+def test_direct_reducers_agree_bitwise_and_with_stepwise_calls(gnn):
+    """The sum of the partial gradients is taken in rank order by every form of the direct reducers -- fused into the tile
+    kernel or flat, all-read-all or reduce-scatter + gather -- and the update has one spelling: the same bits from all of
+    them, whether the steps come as one train_range (successors known: fused) or one call per step (flat kernels)."""
+    B, steps, n_rep = 96, 5, 3
+    X, Y = data(B * 2, seed=41)
+    ws = []
+    for reducer, stepwise in [(gnn.REDUCE_DIRECT, False), (gnn.REDUCE_DIRECT, True), (gnn.REDUCE_DIRECT_RS, False), (gnn.REDUCE_DIRECT_RS, True)]:
+        net = gnn.DataParallelNeuralNet(DIMS, devices=[0] * n_rep, max_batch=B, reducer=reducer)
+        net.upload_dataset(X, Y)
+        if stepwise:
+            for s in range(steps):
+                net.gradient_step_range((s % 2) * B, B, 0.0125, 0.9)
+        else:
+            net.train_range(0, B, steps, 0.0125, 0.9)
+        net.synchronize()
+        assert net.replicas_identical() and net.time == steps
+        ws.append((net.get_weights(), net.get_momentum()))
+    for w, v in ws[1:]:
+        assert np.array_equal(w, ws[0][0]) and np.array_equal(v, ws[0][1])
