@@ -504,7 +504,7 @@ def worker(args, argv):
             # the timed class "grad" is the tile-owner kernel: every layer's gradient + the update + the NEXT batch's
             # first-layer product; "fwd" is the forward-only launch that opens a chain (once per training call)
             names = {"fwd": "tile_step<forward only> (first layer of the chain's first batch, 128x784x300)",
-                     "mid": "middle4 (K-slab sum + f, layers 2.., softmax/CE, backward data)",
+                     "mid": "row-block kernel (K-slab sum + f, layers 2.., softmax/CE, backward data)",
                      "grad": "tile_step (G = A^T.delta all layers + momentum update + next batch's 128x784x300)"}
             kernels = {
                 "fwd": (fwd_us, fwd_n, f01, eo * (BATCH * DIMS[0] + DIMS[0] * DIMS[1]) + 4 * BATCH * DIMS[1]),
@@ -535,7 +535,7 @@ def worker(args, argv):
                 if two_launch:
                     gemm01 = ("upd", f01)
         # kernel names in the PMC file: the two-launch path's kernels first, the three-launch ones as the fallback
-        pmc_key = {"fwd": ["tile_step_kernel<0, 0, true", "fwd_first"], "mid": ["middle4"],
+        pmc_key = {"fwd": ["tile_step_kernel<0, 0, true", "fwd_first"], "mid": ["rowblock", "middle4"],
                    "grad": ["tile_step_kernel<1, 2, true", "grad_update"], "upd": ["tile_step_kernel<2, 2, true", "sgd_momentum"]}
         kernels = {k: v for k, v in kernels.items() if v[1] > 0 and v[0] > 0}
         step_us = dt / K * 1e6

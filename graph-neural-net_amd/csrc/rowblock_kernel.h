@@ -45,7 +45,7 @@ struct RbPlan {
     int ksf[MAX_LAYERS];     // K slices = partial tiles per output element
     int units[MAX_LAYERS];   // 8-row units along K = ld[l] / 8
     int upw[MAX_LAYERS];     // most units one wave takes
-    // backward LDS products giving delta_l, l = L-3..1: column groups of 64 x K slices, dealt to the waves round robin
+    // backward LDS products giving delta_l, l = L-3..1: column groups of 64, dealt to the waves round robin (ksb = 1: no K split)
     int gb[MAX_LAYERS], ksb[MAX_LAYERS];
     int ns;                  // first-layer K slabs
     int lds_floats;
@@ -96,13 +96,9 @@ __host__ __device__ constexpr RbPlan make_rb_plan(const int *dims, int L) {
         if (m.upw[l] > RB_MAXU) return m;
         scratch = rb_max(scratch, m.ksf[l] * 4 * N);
     }
-    for (int l = Lm - 2; l >= 1; l--) { // backward products from the LDS images
-        const int G = (m.kr[l] + 63) / 64, k4n = m.kr[l + 1] / 4;
-        int ks = rb_min(rb_max(1, (2 * RB_NW) / G), k4n); // about two tasks per wave
-        if (ks > 8) ks = 8;
-        m.gb[l] = G;
-        m.ksb[l] = ks;
-        scratch = rb_max(scratch, ks * 4 * G * 64);
+    for (int l = Lm - 2; l >= 1; l--) { // backward products from the LDS images: one wave per group of 64 neurons, whole K
+        m.gb[l] = (m.kr[l] + 63) / 64;
+        m.ksb[l] = 1;
     }
     m.lds_floats = off + scratch + 64;
     if (m.lds_floats * 4 > 160 * 1024 - 256) return m;
@@ -143,6 +139,12 @@ template <int NL> struct RbRuntimeShape {
         if (STAMP && threadIdx.x == 0) p.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();   \
     } while (0)
 
+// per-wave stamps (STAMP builds): region r, 16 slots per workgroup behind the first 16 * gridDim.x
+#define GNN_RB_WSTAMP(r)                                                                                                         \
+    do {                                                                                                                         \
+        if (STAMP && lane == 0) p.stamps[(size_t)(16 * gridDim.x) * (1 + (r)) + blockIdx.x * 16 + wave] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
 // x + (x of the lane 32 away): both halves of the wave end up with the sum.
 // (The two results are copied to scalars before they are reinterpreted: `__builtin_bit_cast(float, r[1])` on the builtin's
 //  vector result read element 0 twice with hipcc 7.2 -- every sum came out as 2 x one half.)
@@ -153,8 +155,58 @@ __device__ __forceinline__ float rb_sum32(float x) {
     return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
 }
 
+// Two tasks of the backward product (delta . W^T from the LDS image, see rowblock_product<true>) interleaved in ONE wave:
+// four independent accumulator chains and the reads of both tasks in flight together -- a lone task is a chain of
+// read - wait - 16 dependent MFMAs per trip, and a wave ran its two tasks one after the other.
+__device__ __forceinline__ void rowblock_backward_pair(const float *A_img, int lda, const float *Wimg, int ldw, int n_rows, int gw, int lane,
+                                                       int kbA, int keA, int n0A, float *partA,
+                                                       bool onB, int kbB, int keB, int n0B, float *partB) {
+    const float *arow = A_img + (lane & 3) * lda;
+    int nA = n0A + lane, nB = n0B + lane;
+    nA = nA < n_rows ? nA : n_rows - 1; // columns past the image compute garbage nobody reads
+    nB = nB < n_rows ? nB : n_rows - 1;
+    const float *wA = Wimg + nA * ldw, *wB = Wimg + nB * ldw;
+    f32x4 accA0 = {0.f, 0.f, 0.f, 0.f}, accA1 = accA0, accB0 = accA0, accB1 = accA0;
+    const int lenA = keA - kbA, lenB = onB ? keB - kbB : 0;
+    const int common = (lenA < lenB ? lenA : lenB) & ~1; // joint trips of two 4-k groups per task: no conditions inside
+    for (int i = 0; i < common; i += 2) { // (bounds are wave-uniform)
+        f32x4 aA[2], bA[2], aB[2], bB[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            aA[u] = *reinterpret_cast<const f32x4 *>(arow + 4 * (kbA + i + u));
+            bA[u] = *reinterpret_cast<const f32x4 *>(wA + 4 * (kbA + i + u));
+            aB[u] = *reinterpret_cast<const f32x4 *>(arow + 4 * (kbB + i + u));
+            bB[u] = *reinterpret_cast<const f32x4 *>(wB + 4 * (kbB + i + u));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            accA0 = __builtin_amdgcn_mfma_f32_4x4x1f32(aA[0][j], bA[0][j], accA0, 0, 0, 0);
+            accB0 = __builtin_amdgcn_mfma_f32_4x4x1f32(aB[0][j], bB[0][j], accB0, 0, 0, 0);
+            accA1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aA[1][j], bA[1][j], accA1, 0, 0, 0);
+            accB1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aB[1][j], bB[1][j], accB1, 0, 0, 0);
+        }
+    }
+    for (int i = common; i < lenA; i++) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 4 * (kbA + i)), b = *reinterpret_cast<const f32x4 *>(wA + 4 * (kbA + i));
+#pragma unroll
+        for (int j = 0; j < 4; j++) accA0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j], b[j], accA0, 0, 0, 0);
+    }
+    for (int i = common; i < lenB; i++) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 4 * (kbB + i)), b = *reinterpret_cast<const f32x4 *>(wB + 4 * (kbB + i));
+#pragma unroll
+        for (int j = 0; j < 4; j++) accB0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j], b[j], accB0, 0, 0, 0);
+    }
+    const f32x4 accA = accA0 + accA1, accB = accB0 + accB1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) partA[r * gw + n0A + lane] = accA[r];
+    if (onB) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) partB[r * gw + n0B + lane] = accB[r];
+    }
+}
+
 // NL > 0: layer count fixed at compile time; IS_STATIC: `m` is a compile-time constant (every extent folds)
-template <int NL, bool IS_STATIC, int ACT_T, int OUTK, bool STAMP, int NSV, int UPW1>
+template <int NL, bool IS_STATIC, int ACT_T, int OUTK, bool STAMP, int NSV, int UPW1, int TUNE>
 __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     const int ACT = (ACT_T >= 0) ? ACT_T : p.inner_act;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -164,83 +216,101 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     const int L = (NL > 0) ? NL : m.L, Lm = L - 1;
     GNN_RB_STAMP(0);
 
-    // ---- phase 0: every load of the kernel is issued here, in the order the data is needed -------------------------
-    // (the row index of a sampled batch's expected row is a DEPENDENT load: issued first, so that waiting for it does not
-    //  drain the queue of everything issued before it -- loads return in order)
+    // ---- phase 0 / 1: loads, and A_1 = f(sum of the slabs, slab order) ------------------------------------------------
+    // What bounds this kernel is the CU's vector-memory pipe: it takes a wave-wide 16-B load in 16 cycles WHATEVER its
+    // lanes carry, and a wave whose requests are queued behind others' STALLS AT ISSUE -- with all 36 loads of a thread
+    // issued up front, issuing alone took 4 000 cycles and the slab sums, long landed, waited behind it
+    // (tools/rowblock_probe stamps).  So the pipe must be kept busy from the first cycle with the fewest instructions:
+    //   * the weights are requested RB_PF units ahead of the MFMAs that consume them, PF0 units before A_1 is formed;
+    //   * only the waves that own an A_1 element issue slab loads (five of eight for 784-300-100-10), in ONE block with the
+    //     sum that consumes them;
+    //   * every load OUTSIDE that block is unconditional (clamped address, never `cond ? offset : 0` on a wave-uniform
+    //     condition): after a branch that contains a load the compiler's wait-count pass drains the whole queue
+    //     (s_waitcnt vmcnt(0)) at the next use of anything loaded.
+    constexpr int RB_PF = 2;                       // weight units requested ahead of the one being multiplied
+    constexpr int PF0 = (TUNE & 7) ? (TUNE & 7) : 2; // units requested before the slabs
+    constexpr bool W_FIRST = (TUNE & 8) == 0;      // the first weight units in front of the slabs in every wave's queue
+    // (the row index of a sampled batch's expected row is a DEPENDENT load: issued first)
     const int qy = m.ld[Lm] >> 2; // 4
     const int y_e = RB_NT - 1 - t, y_r = y_e / qy, y_q = y_e - y_r * qy; // the expected rows: the LAST threads
     const bool y_on = p.Y != nullptr && y_e < 4 * qy;
-    // (unconditional, from an address that is always valid: a load under a branch is waited for at the end of its block)
     const bool y_ix = y_on && p.row_idx != nullptr && row0 + y_r < p.B;
     const int y_ld = *(y_ix ? p.row_idx + (row0 + y_r) : reinterpret_cast<const int32_t *>(p.slabs));
+    // the last weight image (the row tail reads it from LDS): one small load
+    const int c4l = m.kr[Lm] >> 2, nl4 = m.kr[Lm - 1] * c4l; // float4s of the last image's logical columns (<= 128 * 4)
+    const int wl_r = IS_STATIC ? t / c4l : (int)(((unsigned)t * (((1u << 22) + c4l - 1) / c4l)) >> 22), wl_c = t - wl_r * c4l;
+    const f32x4 wl = m4_load16(p.W[Lm - 1], t < nl4 ? (unsigned)(wl_r * m.ld[Lm] + 4 * wl_c) : 0u);
     __builtin_amdgcn_sched_barrier(0);
-    // (a) the first-layer K slabs: one float4 of the four A_1 rows per thread, all slabs of it
-    const int q1 = m.ld[1] >> 2;
-    const bool a1_on = t < 4 * q1;
-    const int a1_r = IS_STATIC ? t / q1 : (int)(((unsigned)t * (((1u << 22) + q1 - 1) / q1)) >> 22), a1_q = t - a1_r * q1;
-    f32x4 zs[NSV];
-    {
-        const unsigned zoff = a1_on ? (unsigned)(row0 + a1_r) * (unsigned)m.ld[1] + (unsigned)(a1_q * 4) : 0u;
-        const unsigned sstride = (unsigned)p.slab_rows * (unsigned)m.ld[1];
-#pragma unroll
-        for (int i = 0; i < NSV; i++) {
-            zs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (i < m.ns) zs[i] = m4_load16(p.slabs, zoff + (a1_on ? (unsigned)i * sstride : 0u));
-        }
-    }
-    // Issue order = the order the data is needed in.  Within a wave loads return in order; ACROSS the waves the memory
-    // pipeline serves requests roughly as they arrive, so every wave's slab requests are put in front of any wave's weight
-    // requests: a bare barrier (nothing is waited for) between the two groups.  Without it A_1 was ready only when the
-    // weights had landed too (5 500 cycles after the start instead of ~2 500: tools/rowblock_probe).
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // (b) this wave's K slice of the first register product (W_1 -> layer 2): 8-row units, 16 B per lane
+    // this wave's K slice of the first register product (W_1 -> layer 2): 8-row units, 16 B per lane
     //     lane (hq, lq): rows 8u + 4hq + 0..3 of the unit, columns 128 cslice + 4 lq .. +3
     const int hq = lane >> 5, lq = lane & 31;
     const int rot = (blockIdx.x >> 3) & 3; // the four workgroups of an XCD start their weight streams at different slices
     f32x4 w1[UPW1 > 0 ? UPW1 : 1][4];
-    int u0_1 = 0, nu_1 = 0, s_1 = 0, c_1 = 0;
-    if (UPW1 > 0 && Lm >= 3) { // (a net of three layers has no register product: its only middle matrix is the row tail's)
-        const int l = 1;
-        const int CS = m.cs[l], KS = m.ksf[l], U = m.units[l];
-        c_1 = wave & (CS - 1);
-        s_1 = (wave / CS + rot * ((KS + 3) >> 2)) % KS;
-        u0_1 = (s_1 * U) / KS;
-        nu_1 = ((s_1 + 1) * U) / KS - u0_1;
-        const int col = 128 * c_1 + 4 * lq;
-        const bool lane_on = col < m.ld[l + 1];
+    int u0_1 = 0, nu_1 = 0;
+    // (uu: compile-time after unrolling.  No select on the address: a unit past the wave's slice is CLAMPED to the last
+    //  unit of the matrix and a lane past the last column to the last float4 of the row -- valid addresses whose data is
+    //  never used.)
+    int ulast_1 = 0, colc_1 = 0;
+    auto load_unit_1 = [&](int uu) {
+        const int u = u0_1 + uu < ulast_1 ? u0_1 + uu : ulast_1;
 #pragma unroll
-        for (int uu = 0; uu < UPW1; uu++) {
-            const bool on = lane_on && uu < nu_1;
+        for (int tt = 0; tt < 4; tt++) {
+            const int k = 8 * u + 4 * hq + tt;
+            w1[UPW1 > 0 ? uu : 0][tt] = m4_load16(p.W[1], (unsigned)(k * m.ld[2] + colc_1));
+        }
+    };
+    // The copy of a wave's weight rows to the LDS image (for the backward product) costs the LDS store path 13 cycles per
+    // 16-B write, 160 writes in all.  The waves whose threads sum the K slices afterwards (the first ceil(4 N / 4 / 64) of
+    // them) do it between their MFMAs; the others wait until THEY are idle -- the slice sum -- so that neither the
+    // product nor the row tail (whose LDS reads queued behind these writes when they ran beside it) pays for it.
+    constexpr bool DEFER = (TUNE & 16) == 0;
+    constexpr int n_sum_waves = 4; // the row-tail waves copy between their MFMAs, waves 4..7 while the row tail runs
+    int col_1 = 0;
+    auto to_image_1 = [&](int uu) { // the rows this wave holds of unit uu, for the backward product
+        if (col_1 < m.kr[2]) {
 #pragma unroll
             for (int tt = 0; tt < 4; tt++) {
                 const int k = 8 * (u0_1 + uu) + 4 * hq + tt;
-                w1[uu][tt] = m4_load16(p.W[l], on ? (unsigned)(k * m.ld[l + 1] + col) : 0u);
+                if (k < m.kr[1]) *reinterpret_cast<f32x4 *>(smem + m.off_w[1] + k * m.lw[1] + col_1) = w1[UPW1 > 0 ? uu : 0][tt];
             }
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // (c) the expected rows and the last weight image (the row tail reads it from LDS): small, needed last, issued last
-    const int y_idx = p.row_idx ? (y_ix ? y_ld : 0) : row0 + y_r; // rows past the batch are masked below
-    const f32x4 yv = *reinterpret_cast<const f32x4 *>((p.Y ? p.Y : p.slabs) + (y_on ? (size_t)y_idx * p.ldy + y_q * 4 : (size_t)0));
-    const int c4l = m.kr[Lm] >> 2, nl4 = m.kr[Lm - 1] * c4l; // float4s of the last image's logical columns (<= 128 * 4)
-    const int wl_r = IS_STATIC ? t / c4l : (int)(((unsigned)t * (((1u << 22) + c4l - 1) / c4l)) >> 22), wl_c = t - wl_r * c4l;
-    const f32x4 wl = m4_load16(p.W[Lm - 1], t < nl4 ? (unsigned)(wl_r * m.ld[Lm] + 4 * wl_c) : 0u);
-    // (no register pins here: an `asm volatile("" : "+v"(x))` READS x, i.e. waits for its load -- the compiler cannot move
-    //  these loads below the global store of A_1 in phase 1, which may alias them)
-    __builtin_amdgcn_sched_barrier(0);
-    auto tail_operands_to_lds = [&]() {
-        if (y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv;
-        if (t < nl4) *reinterpret_cast<f32x4 *>(smem + m.off_w[Lm - 1] + wl_r * m.lw[Lm - 1] + 4 * wl_c) = wl;
     };
-
-    // ---- phase 1: A_1 = f(sum of the slabs, slab order) -------------------------------------------------------------
-    {
+    if (UPW1 > 0 && Lm >= 3) { // (a net of three layers has no register product: its only middle matrix is the row tail's)
+        const int CS = m.cs[1], KS = m.ksf[1], U = m.units[1];
+        const int c_1 = wave & (CS - 1), s_1 = (wave / CS + rot * ((KS + 3) >> 2)) % KS;
+        u0_1 = (s_1 * U) / KS;
+        nu_1 = ((s_1 + 1) * U) / KS - u0_1;
+        col_1 = 128 * c_1 + 4 * lq;
+        colc_1 = col_1 < m.ld[2] ? col_1 : m.ld[2] - 4;
+        ulast_1 = U - 1;
+    }
+    if constexpr (UPW1 > 0 && W_FIRST) {
+#pragma unroll
+        for (int uu = 0; uu < UPW1; uu++)
+            if (uu < PF0) load_unit_1(uu);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the first-layer K slabs: one float4 of the four A_1 rows per thread, all slabs of it; slab order; then f.
+    // Rows past the batch and columns past d_1 are zeros (f(0) != 0 for the sigmoid).
+    const int q1 = m.ld[1] >> 2;
+    if (wave * 64 < 4 * q1) { // (wave-uniform)
+        if (TUNE & 64) { if (wave >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); } // the slab waves over the others; the younger one of a SIMD first
+        const bool a1_on = t < 4 * q1;
+        const int a1_r = IS_STATIC ? t / q1 : (int)(((unsigned)t * (((1u << 22) + q1 - 1) / q1)) >> 22), a1_q = t - a1_r * q1;
+        const unsigned zoff = a1_on ? (unsigned)(row0 + a1_r) * (unsigned)m.ld[1] + (unsigned)(a1_q * 4) : 0u;
+        const unsigned sstride = (unsigned)p.slab_rows * (unsigned)m.ld[1];
+        f32x4 zs[NSV];
+#pragma unroll
+        for (int i = 0; i < NSV; i++) {
+            const unsigned o = zoff + (a1_on ? (unsigned)i * sstride : 0u);
+            zs[i] = m4_load16(p.slabs, i < m.ns ? o : 0u); // (runtime shapes: the slots past n_slabs re-read offset 0 and are not summed)
+        }
+        GNN_RB_STAMP(6); // this wave's phase-0 loads issued
         f32x4 z = zs[0];
 #pragma unroll
         for (int i = 1; i < NSV; i++)
             if (i < m.ns) z += zs[i];
+        if (STAMP) { asm volatile("" : "+v"(z)); GNN_RB_STAMP(7); } // this wave's slabs have landed
         const bool lrow = row0 + a1_r < p.B;
         f32x4 a;
 #pragma unroll
@@ -249,8 +319,21 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
             *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a;
             *reinterpret_cast<f32x4 *>(p.act[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) = a; // the tile kernel reads A_1
         }
-        if (Lm < 3) tail_operands_to_lds(); // (no register product in front of the row tail)
+        if (TUNE & 64) __builtin_amdgcn_s_setprio(0);
     }
+    if constexpr (UPW1 > 0 && !W_FIRST) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int uu = 0; uu < UPW1; uu++)
+            if (uu < PF0) load_unit_1(uu);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the row tail's weight image (requested first) and the expected rows (the index of a sampled batch's row has long landed)
+    if (t < nl4) *reinterpret_cast<f32x4 *>(smem + m.off_w[Lm - 1] + wl_r * m.lw[Lm - 1] + 4 * wl_c) = wl;
+    const int y_idx = p.row_idx ? (y_ix ? y_ld : 0) : row0 + y_r; // rows past the batch are masked below
+    const f32x4 yv = *reinterpret_cast<const f32x4 *>((p.Y ? p.Y : p.slabs) + (y_on ? (size_t)y_idx * p.ldy + y_q * 4 : (size_t)0));
+    if (Lm < 3 && y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv; // (no register product in front of the row tail)
+    GNN_RB_WSTAMP(0); // this wave at the A_1 barrier
     __syncthreads();
     GNN_RB_STAMP(1);
 
@@ -283,11 +366,29 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
             }
         };
         if (l == 1 && UPW1 > 0) {
-            // a unit's rows go to the LDS image right behind its MFMAs: the writes (13 cycles of the LDS store path each) run
-            // under the matrix pipe's 128 cycles per unit and under the wait for the next unit's loads
+            // the A operands of every unit (4 rows x 8 k each) are read at once, behind the barrier: one LDS round trip
+            f32x4 av1[UPW1 > 0 ? UPW1 : 1];
 #pragma unroll
-            for (int uu = 0; uu < UPW1; uu++)
-                if (uu < nu) { unit(u0 + uu, w1[uu]); to_image(u0 + uu, w1[uu]); }
+            for (int uu = 0; uu < UPW1; uu++) av1[uu] = *reinterpret_cast<const f32x4 *>(arow + 8 * (u0 + (uu < nu ? uu : 0)));
+            // software pipeline over the wave's units: request unit uu + RB_PF, multiply unit uu, copy its rows to the LDS
+            // image for the backward product (13 cycles of the LDS store path per write, under the matrix pipe's 128 per unit)
+#pragma unroll
+            for (int uu = 0; uu < UPW1; uu++) {
+                if (uu + RB_PF >= PF0 && uu + RB_PF < UPW1) load_unit_1(uu + RB_PF);
+                if (uu == 0) { // (PF0 < RB_PF: catch up)
+#pragma unroll
+                    for (int v = PF0; v < RB_PF && v < UPW1; v++) load_unit_1(v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (uu < nu) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(av1[uu][tt], w1[uu][tt][j], acc[j], 0, 0, 0);
+                    if (!DEFER || wave < n_sum_waves) to_image_1(uu);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
             // later layers (nets of five and more layers): the slice is loaded here, RB_MAXU units at a time
             for (int ub = 0; ub < nu; ub += RB_MAXU) {
@@ -303,26 +404,26 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                 }
 #pragma unroll
                 for (int uu = 0; uu < RB_MAXU; uu++)
-#pragma unroll
-                    for (int tt = 0; tt < 4; tt++) asm volatile("" : "+v"(w[uu][tt]));
-#pragma unroll
-                for (int uu = 0; uu < RB_MAXU; uu++)
                     if (ub + uu < nu) { unit(u0 + ub + uu, w[uu]); to_image(u0 + ub + uu, w[uu]); }
             }
         }
-        if (l == 1) tail_operands_to_lds(); // behind this wave's weight loads in the queue: waiting for them here costs nothing
+        if (STAMP) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); GNN_RB_STAMP(8); } // MFMAs + image writes issued, results in
+        if (l == 1 && y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv;
         // the two half-waves sat at different k: add them, then the slice's partial tile, 16 B per row and lane
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[j][r] = rb_sum32(acc[j][r]);
+        if (l == 1) GNN_RB_WSTAMP(1); // this wave's MFMAs done
         if (hq == 0 && lane_on) {
             float *part = smem + m.off_scratch + (s * 4) * N + col;
 #pragma unroll
             for (int r = 0; r < 4; r++) *reinterpret_cast<f32x4 *>(part + r * N) = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
         }
+        if (l == 1) GNN_RB_WSTAMP(2); // this wave at the partial-tile barrier
         __syncthreads();
         GNN_RB_STAMP(2 * l);
+        if (l + 1 == Lm - 1) break; // the layer the row tail reads: its wave sums its own row's slices (no barrier: same wave)
         // K slices summed in slice order, f applied: 4 x N/4 float4s over the threads
         const int n4 = N >> 2;
         for (int e = t; e < 4 * n4; e += RB_NT) {
@@ -341,81 +442,157 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     }
 
     // ---- row tail: one wave per batch row does the last layer, the output rule and delta_{L-2} ------------------------
+    // A lone wave hides no latency, so the chain is kept short: lane (kg = lane / 4, q = lane % 4) multiplies rows
+    // k = kg, kg + 16, .. of the last weight image with the float4 of columns 4q..4q+3 -- every LDS read of the logits is in
+    // flight at once (<= 8 + 8 reads instead of 25 dependent rounds of two), the 16 k groups meet by two DPP rotations and
+    // two lane exchanges, and the output rule runs on the quad (q = 0..3 holds the 16 padded classes).
     if (wave < 4) {
+        if (TUNE & 32) __builtin_amdgcn_s_setprio(3); // the four waves on the critical path, over the image copies of the other four
         const int r = wave, row = row0 + r;
         const int K = m.kr[Lm - 1], nt = m.d[Lm], lwl = m.lw[Lm - 1], ldp = m.ld[Lm - 1];
+        if (Lm >= 3) {
+            // this row of the last hidden layer: K slices summed in slice order, f applied (N <= 128: one float4 per lane)
+            const int l = Lm - 2, N = ldp, KS = m.ksf[l], n = 4 * lane;
+            if (n < N) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < m.kr[l + 1])
+                    for (int ks = 0; ks < KS; ks++) v += *reinterpret_cast<const f32x4 *>(smem + m.off_scratch + (ks * 4 + r) * N + n);
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = (row < p.B && n + j < m.d[l + 1]) ? act_fn(ACT, v[j]) : 0.f;
+                *reinterpret_cast<f32x4 *>(p.act[l + 1] + (size_t)row * N + n) = v;
+                *reinterpret_cast<f32x4 *>(smem + m.off_act[l + 1] + r * (N + 4) + n) = v; // (read back below by this very wave)
+            }
+        }
         const float *a = smem + m.off_act[Lm - 1] + r * (ldp + 4);
         const float *Wl = smem + m.off_w[Lm - 1];
-        const int ks = lane >> 4, c = lane & 15;
-        // logits: lane (ks, c) sums k = ks, ks+4, .. of column c; the four partial sums meet by lane exchange
-        float zv = 0.f;
-        if (c < m.kr[Lm]) {
-            constexpr int UK = 8; // reads of 8 steps in flight before their FMAs: a lone wave hides no LDS latency
-            int k = ks;
-            for (; k + 4 * (UK - 1) < K; k += 4 * UK) {
-                float av[UK], wv[UK];
+        const int kg = lane >> 2, q = lane & 3;
+        const bool q_on = 4 * q < m.kr[Lm];        // (the image holds kr[Lm] <= 16 columns)
+        constexpr int TK = 8;                      // K <= 128 = 16 k groups x 8
+        f32x4 w4[TK];
+        float av[TK];
 #pragma unroll
-                for (int u = 0; u < UK; u++) { av[u] = a[k + 4 * u]; wv[u] = Wl[(k + 4 * u) * lwl + c]; }
-#pragma unroll
-                for (int u = 0; u < UK; u++) zv = __builtin_fmaf(av[u], wv[u], zv);
-            }
-            for (; k < K; k += 4) zv = __builtin_fmaf(a[k], Wl[k * lwl + c], zv);
+        for (int i = 0; i < TK; i++) {
+            const int k = kg + 16 * i;
+            const bool on = k < K && q_on;
+            w4[i] = *reinterpret_cast<const f32x4 *>(Wl + (on ? k * lwl + 4 * q : 0));
+            av[i] = on ? a[k] : 0.f;
         }
-        zv += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __builtin_bit_cast(int, zv)));
-        zv += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, zv)));
-        // output rule on the DPP row of 16 (all four rows of the wave hold the same 16 logits)
-        const bool valid = c < nt, live = row < p.B && valid;
-        const float yy = (live && p.Y) ? smem[m.off_y + r * 16 + c] : 0.f;
-        float out, dd, lterm, mx;   // reported output, delta, this lane's loss term, argmax key
-        int best = valid ? c : -1;
-        float nan_flag = 0.f;
-        float lse = 0.f;
+        f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TK; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) z4[j] = __builtin_fmaf(av[i], w4[i][j], z4[j]);
+        if (STAMP) { asm volatile("" : "+v"(z4)); GNN_RB_STAMP(9); } // logits: reads + FMAs
+#pragma unroll
+        for (int j = 0; j < 4; j++) { // the 16 k groups: lanes q, q+4, q+8, q+12 of every row of 16, then the four rows
+            float v = z4[j];
+            v += dpp_f<0x128>(v);  // row_ror:8
+            v += dpp_f<0x124>(v);  // row_ror:4
+            v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __builtin_bit_cast(int, v)));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
+            z4[j] = v;
+        }
+        if (STAMP) { asm volatile("" : "+v"(z4)); GNN_RB_STAMP(10); } // k groups reduced
+        // output rule on the quad: lane q holds classes 4q..4q+3
+        constexpr int QX1 = 0xB1, QX2 = 0x4E; // quad_perm [1,0,3,2] / [2,3,0,1]
+        const f32x4 y4 = (row < p.B && p.Y) ? *reinterpret_cast<const f32x4 *>(smem + m.off_y + r * 16 + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 out4 = {0.f, 0.f, 0.f, 0.f}, dd4 = {0.f, 0.f, 0.f, 0.f};
+        float lsum = 0.f, mx = -__builtin_inff(), nan_flag = 0.f;
+        int best = -1;
+        bool valid[4], live[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { valid[j] = 4 * q + j < nt; live[j] = valid[j] && row < p.B; }
+        auto quad_argmax = [&](float &v, int &ix) { // larger value wins, ties -> higher index (MT:166-168)
+#define GNN_RB_QSTEP(CTRL)                                              \
+            {                                                            \
+                const float ov = dpp_f<CTRL>(v);                         \
+                const int oi = dpp_i<CTRL>(ix);                          \
+                const bool tk = (ov > v) | ((ov == v) & (oi > ix));         \
+                v = tk ? ov : v; ix = tk ? oi : ix;                      \
+            }
+            GNN_RB_QSTEP(QX1)
+            GNN_RB_QSTEP(QX2)
+#undef GNN_RB_QSTEP
+        };
+        // (selects, not branches: every `if` on a lane value here became a save-exec region with its own waits)
         if (OUTK == 0) {
-            mx = valid ? zv : -__builtin_inff();
-            if (p.label) { // MT:166-168 incl. the NaN rule (see output_layer_kernel): any NaN logit -> label 0
-                nan_flag = (valid && zv != zv) ? 1.f : 0.f;
-                row16_argmax(mx, best);
-            } else {
-                mx = row16_max(mx);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float zj = z4[j];
+                nan_flag = (valid[j] & (zj != zj)) ? 1.f : nan_flag;      // any NaN logit -> label 0 (see output_layer_kernel)
+                const bool take = valid[j] & (zj >= mx);                  // `>=`: ties -> the higher index
+                mx = take ? zj : mx;
+                best = take ? 4 * q + j : best;
             }
-            const float e = valid ? __expf(zv - mx) : 0.f;
-            const float ssum = row16_sum(e);
-            out = live ? e * (1.f / ssum) : 0.f;
-            dd = live ? out - yy : 0.f;                          // SCE:250
-            if (p.loss) lse = mx + __logf(ssum);
-            lterm = (live && yy != 0.f) ? yy * (lse - zv) : 0.f; // -y ln p, SCE:216
+            if (p.label) quad_argmax(mx, best);
+            else { mx = fmaxf(mx, dpp_f<QX1>(mx)); mx = fmaxf(mx, dpp_f<QX2>(mx)); }
+            f32x4 e4;
+            float ssum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { e4[j] = valid[j] ? __expf(z4[j] - mx) : 0.f; ssum += e4[j]; }
+            ssum += dpp_f<QX1>(ssum);
+            ssum += dpp_f<QX2>(ssum);
+            const float inv = 1.f / ssum;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                out4[j] = live[j] ? e4[j] * inv : 0.f;
+                dd4[j] = live[j] ? out4[j] - y4[j] : 0.f;                              // SCE:250
+            }
+            if (p.loss) { // (kernel argument: a scalar branch)
+                const float lse = mx + __logf(ssum);
+#pragma unroll
+                for (int j = 0; j < 4; j++) lsum += (live[j] & (y4[j] != 0.f)) ? y4[j] * (lse - z4[j]) : 0.f; // -y ln p, SCE:216
+            }
         } else {
-            const float av = act_fn(p.last_act, zv);             // GNN:215-218
-            const float df = av - yy;
-            out = live ? av : 0.f;
-            dd = live ? df * act_prime_from_a(p.last_act, av) : 0.f; // GNN:267-271
-            lterm = live ? 0.5f * df * df : 0.f;
-            const bool in_scan = live && av == av;               // `x >= NaN` and `NaN >= x` are false: a NaN is never selected
-            mx = in_scan ? av : -__builtin_inff();
-            if (!in_scan) best = -1;
-            if (p.label) { // element-wise output: only a NaN at index 0 is sticky (MT:166-168)
-                nan_flag = (live && c == 0 && av != av) ? 1.f : 0.f;
-                row16_argmax(mx, best);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float avj = act_fn(p.last_act, z4[j]);                           // GNN:215-218
+                const float df = avj - y4[j];
+                out4[j] = live[j] ? avj : 0.f;
+                dd4[j] = live[j] ? df * act_prime_from_a(p.last_act, avj) : 0.f;       // GNN:267-271
+                lsum += live[j] ? 0.5f * df * df : 0.f;
+                nan_flag = (live[j] & (4 * q + j == 0) & (avj != avj)) ? 1.f : nan_flag; // only a NaN at index 0 is sticky
+                const bool take = live[j] & (avj >= mx);                               // a NaN is never selected
+                mx = take ? avj : mx;
+                best = take ? 4 * q + j : best;
             }
+            if (p.label) quad_argmax(mx, best);
         }
-        if (p.label && row16_sum(nan_flag) > 0.f) best = 0;
-        float *dlast = smem + m.off_dl[Lm] + r * (16 + 4);
-        if (ks == 0) {
-            if (p.prob) p.prob[(size_t)row * 16 + c] = out;
-            dlast[c] = dd;
-            p.delta[Lm][(size_t)row * 16 + c] = dd;
+        if (p.label) {
+            nan_flag += dpp_f<QX1>(nan_flag);
+            nan_flag += dpp_f<QX2>(nan_flag);
+            if (nan_flag > 0.f) best = 0;
         }
         if (p.loss) {
-            const float lsum = row16_sum(lterm);
-            if (lane == 0) p.loss[row] = row < p.B ? lsum : 0.f;
+            lsum += dpp_f<QX1>(lsum);
+            lsum += dpp_f<QX2>(lsum);
         }
-        if (p.label && lane == 0) p.label[row] = row < p.B ? best : -1;
-        if (Lm - 1 >= 1) {
-            // delta_{L-2}[n] = (sum_c delta_{L-1}[c] W[n][c]) f'(a[n]): lane n and n + 64; the wave reads back
-            // its own 16 deltas (LDS keeps a wave's accesses in order); only the copied columns of W are used
-            f32x4 d4[4];
+        if (STAMP) { asm volatile("" : "+v"(dd4)); GNN_RB_STAMP(11); } // output rule done
+        float *dlast = smem + m.off_dl[Lm] + r * (16 + 4);
+        if (kg == 0) {
+            if (p.prob) *reinterpret_cast<f32x4 *>(p.prob + (size_t)row * 16 + 4 * q) = out4;
+            *reinterpret_cast<f32x4 *>(dlast + 4 * q) = dd4;
+            *reinterpret_cast<f32x4 *>(p.delta[Lm] + (size_t)row * 16 + 4 * q) = dd4;
+        }
+        if (lane == 0) {
+            if (p.loss) p.loss[row] = row < p.B ? lsum : 0.f;
+            if (p.label) p.label[row] = row < p.B ? best : -1;
+        }
+        {
+            // delta_{L-2}[n] = (sum_c delta_{L-1}[c] W[n][c]) f'(a[n]): lane n and n + 64, both halves' reads in flight together;
+            // the wave reads back its own 16 deltas (LDS keeps a wave's accesses in order); only the copied columns of W are used
+            f32x4 d4[4], wn[2][4];
+            float an[2];
 #pragma unroll
-            for (int q = 0; q < 4; q++) d4[q] = *reinterpret_cast<const f32x4 *>(dlast + 4 * q);
+            for (int qq = 0; qq < 4; qq++) d4[qq] = *reinterpret_cast<const f32x4 *>(dlast + 4 * qq);
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int n = lane + 64 * half;
+                const bool on = n < K;
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) wn[half][qq] = *reinterpret_cast<const f32x4 *>(Wl + ((on && 4 * qq < m.kr[Lm]) ? n * lwl + 4 * qq : 0));
+                an[half] = a[n < ldp ? n : 0];
+            }
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const int n = lane + 64 * half;
@@ -423,50 +600,73 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                     float accd = 0.f;
                     if (n < K) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            if (4 * q < m.kr[Lm]) {
-                                const f32x4 w4 = *reinterpret_cast<const f32x4 *>(Wl + n * lwl + 4 * q);
+                        for (int qq = 0; qq < 4; qq++)
+                            if (4 * qq < m.kr[Lm])
 #pragma unroll
-                                for (int j = 0; j < 4; j++) accd = __builtin_fmaf(d4[q][j], w4[j], accd);
-                            }
-                        }
+                                for (int j = 0; j < 4; j++) accd = __builtin_fmaf(d4[qq][j], wn[half][qq][j], accd);
                     }
-                    const float v = (row < p.B && n < m.d[Lm - 1]) ? accd * act_prime_from_a(ACT, a[n]) : 0.f;
+                    const float v = (row < p.B && n < m.d[Lm - 1]) ? accd * act_prime_from_a(ACT, an[half]) : 0.f;
                     if (Lm - 1 > 1) smem[m.off_dl[Lm - 1] + r * (ldp + 4) + n] = v;
                     p.delta[Lm - 1][(size_t)row * ldp + n] = v;
                 }
             }
         }
     }
+    else if (DEFER && UPW1 > 0 && Lm >= 3) {
+#pragma unroll
+        for (int uu = 0; uu < UPW1; uu++)
+            if (uu < nu_1) to_image_1(uu);
+    }
+    if (TUNE & 32) __builtin_amdgcn_s_setprio(0);
+    GNN_RB_STAMP(4);  // wave 0's tail done
+    GNN_RB_WSTAMP(3); // this wave at the end of the row-tail phase
     __syncthreads();
     GNN_RB_STAMP(12);
 
     // ---- backward data: delta_l = (delta_{l+1} . W_l^T) * f'(z_l), l = L-3 .. 1 (SCE:262-278), from the LDS images ------
+    // One wave per group of 64 neurons over the WHOLE contraction: the four rows' sums stay in the accumulators and f',
+    // the mask and the stores follow at once -- no K split, no partial tiles, no barrier before the epilogue (the split
+    // form spent 3 400 cycles on a product whose MFMAs take ~1 000).
 #pragma unroll
     for (int li = 0; li < MAX_LAYERS; li++) {
         const int l = Lm - 2 - li;
         if (l < 1) break;
-        const int N = m.ld[l], NR = m.kr[l], G = m.gb[l], gw = G * 64, KS = m.ksb[l];
+        const int N = m.ld[l], NR = m.kr[l], G = m.gb[l];
         const int k4n = m.kr[l + 1] / 4;
-        for (int task = wave; task < G * KS; task += RB_NW) { // (wave-uniform)
-            const int g = task % G, ks = task / G;
-            rowblock_product<true>(smem + m.off_dl[l + 1], m.ld[l + 1] + 4, smem + m.off_w[l], m.lw[l],
-                                   ks * k4n / KS, (ks + 1) * k4n / KS, g * 64, NR,
-                                   smem + m.off_scratch + ks * 4 * gw, gw, lane);
-        }
-        __syncthreads();
-        const int n4 = N >> 2;
-        for (int e = t; e < 4 * n4; e += RB_NT) {
-            const int er = IS_STATIC ? e / n4 : (int)(((unsigned)e * (((1u << 22) + n4 - 1) / n4)) >> 22), n = 4 * (e - er * n4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < NR)
-                for (int ks = 0; ks < KS; ks++) v += *reinterpret_cast<const f32x4 *>(smem + m.off_scratch + (ks * 4 + er) * gw + n);
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(smem + m.off_act[l] + er * (N + 4) + n); // f'(z_l) from a_l = f(z_l)
-            const bool lrow = row0 + er < p.B;
+        for (int g = wave; g < G; g += RB_NW) { // (wave-uniform)
+            const int n = g * 64 + lane;
+            const float *arow = smem + m.off_dl[l + 1] + (lane & 3) * (m.ld[l + 1] + 4);
+            const float *wp = smem + m.off_w[l] + (n < NR ? n : NR - 1) * m.lw[l]; // columns past the image compute garbage nobody stores
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            constexpr int U = 4;
+            int kb = 0;
+            for (; kb + U <= k4n; kb += U) {
+                f32x4 a[U], b[U];
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = (lrow && n + j < m.d[l]) ? v[j] * act_prime_from_a(ACT, a[j]) : 0.f;
-            *reinterpret_cast<f32x4 *>(p.delta[l] + (size_t)(row0 + er) * N + n) = v;
-            if (l > 1) *reinterpret_cast<f32x4 *>(smem + m.off_dl[l] + er * (N + 4) + n) = v;
+                for (int u = 0; u < U; u++) { a[u] = *reinterpret_cast<const f32x4 *>(arow + 4 * (kb + u)); b[u] = *reinterpret_cast<const f32x4 *>(wp + 4 * (kb + u)); }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u][j], b[u][j], acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u][j], b[u][j], acc0, 0, 0, 0);
+                    }
+            }
+            for (; kb < k4n; kb++) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 4 * kb), b = *reinterpret_cast<const f32x4 *>(wp + 4 * kb);
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j], b[j], acc0, 0, 0, 0);
+            }
+            const f32x4 acc = acc0 + acc1; // register r of lane: delta_l[row r][n] before f'
+            if (n < N) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float al = smem[m.off_act[l] + r * (N + 4) + n]; // f'(z_l) from a_l = f(z_l)
+                    const float v = (row0 + r < p.B && n < m.d[l]) ? acc[r] * act_prime_from_a(ACT, al) : 0.f;
+                    p.delta[l][(size_t)(row0 + r) * N + n] = v;
+                    if (l > 1) smem[m.off_dl[l] + r * (N + 4) + n] = v;
+                }
+            }
         }
         if (l > 1) __syncthreads();
         GNN_RB_STAMP(13);
@@ -474,14 +674,15 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     GNN_RB_STAMP(14);
 }
 
-template <class SH, int ACT, int OUTK, bool STAMP = false>
+// TUNE: development knob of tools/rowblock_probe (0 = the shipped schedule)
+template <class SH, int ACT, int OUTK, bool STAMP = false, int TUNE = 0>
 __global__ __launch_bounds__(RB_NT) void rowblock_kernel(RbParams p) {
     if constexpr (SH::is_static) {
         constexpr RbPlan m = SH::make(); // a LOCAL constexpr object: member accesses with constant indices fold to immediates
         static_assert(m.ok, "this shape does not fit the row-block kernel");
-        rowblock_body<SH::kL, true, ACT, OUTK, STAMP, m.ns, (SH::kL >= 4 ? m.upw[1] : 0)>(m, p);
+        rowblock_body<SH::kL, true, ACT, OUTK, STAMP, m.ns, (SH::kL >= 4 ? m.upw[1] : 0), TUNE>(m, p);
     } else {
-        rowblock_body<SH::kL, false, ACT, OUTK, STAMP, MID4_MAX_SLABS, (SH::kL == 3 ? 0 : RB_MAXU)>(p.plan, p);
+        rowblock_body<SH::kL, false, ACT, OUTK, STAMP, MID4_MAX_SLABS, (SH::kL == 3 ? 0 : RB_MAXU), TUNE>(p.plan, p);
     }
 }
 

@@ -51,11 +51,9 @@ int main(int argc, char **argv) {
     auto k_old = middle4_kernel<SS, 0, 0, true, false, true>;
     auto k_new = rowblock_kernel<RS, 0, 0, false>;
     auto k_new_rt = rowblock_kernel<RbRuntimeShape<4>, -1, 0, false>;
-    auto k_new_st = rowblock_kernel<RS, 0, 0, true>;
     CK(hipFuncSetAttribute((const void *)k_old, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     CK(hipFuncSetAttribute((const void *)k_new, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
     CK(hipFuncSetAttribute((const void *)k_new_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
-    CK(hipFuncSetAttribute((const void *)k_new_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     const dim3 grid((B + 3) / 4);
     auto compare = [&](const char *name) {
@@ -87,20 +85,40 @@ int main(int argc, char **argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-44s %8.2f us per call\n", name, ms * 1000.f / n);
     };
-    for (int rep = 0; rep < 2; rep++) {
-        time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
-        time_it("rowblock<static> (8 waves)", 500, [&]() { hipLaunchKernelGGL(k_new, grid, dim3(RB_NT), ldsr, s, rb); });
-        time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, rb); });
-    }
-    CK(hipMemsetAsync(stamps, 0, 4096 * 16 * 8, s));
-    hipLaunchKernelGGL(k_new_st, grid, dim3(RB_NT), ldsr, s, rb);
-    CK(hipStreamSynchronize(s));
-    std::vector<unsigned long long> hs((size_t)32 * 16);
-    CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
-    for (int w : {0, 7, 16, 31}) {
-        const unsigned long long *q = &hs[w * 16];
-        printf("rowblock wg%-2d: slabs->A1 %llu | L2 product %llu | L2 reduce %llu | row tail %llu | backward %llu | total %llu cycles\n", w,
-               q[1] - q[0], q[2] - q[1], q[3] - q[2], q[12] - q[3], q[14] - q[12], q[14] - q[0]);
-    }
+    auto stamps_of = [&](const char *name, auto kst) {
+        CK(hipFuncSetAttribute((const void *)kst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+        CK(hipMemsetAsync(stamps, 0, 4096 * 16 * 8, s));
+        hipLaunchKernelGGL(kst, grid, dim3(RB_NT), ldsr, s, rb);
+        CK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> hs((size_t)32 * 16 * 5);
+        CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        for (int w : {0, 16}) {
+            const unsigned long long *q = &hs[w * 16];
+            printf("%s wg%-2d: slabs->A1 %llu (wave 0: loads issued +%llu, slabs in +%llu) | L2 product %llu (wave 0 done +%llu) | L2 reduce %llu | row tail %llu | backward %llu | total %llu cycles\n", name, w,
+                   q[1] - q[0], q[6] - q[0], q[7] - q[0], q[2] - q[1], q[8] - q[1], q[3] - q[2], q[12] - q[3], q[14] - q[12], q[14] - q[0]);
+            printf("    tail of wave 0 (from the reduce barrier): logits +%llu | k groups reduced +%llu | output rule +%llu | stores + delta_{L-2} +%llu\n", q[9] - q[3], q[10] - q[3], q[11] - q[3], q[4] - q[3]);
+            const char *rn[4] = {"at A1 barrier", "MFMAs done", "at partial barrier", "tail phase end"};
+            for (int r = 0; r < 4; r++) {
+                printf("    waves %-18s (from start):", rn[r]);
+                for (int v = 0; v < 8; v++) printf(" %6lld", (long long)(hs[(size_t)(16 * 32) * (1 + r) + w * 16 + v] - q[0]));
+                printf("\n");
+            }
+        }
+    };
+#define VARIANT(T) do { \
+        auto kv = rowblock_kernel<RS, 0, 0, false, T>; \
+        CK(hipFuncSetAttribute((const void *)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr)); \
+        for (int l = 1; l < L; l++) { CK(hipMemset(act[1][l], 0xff, (size_t)Bp * ld[l] * 4)); CK(hipMemset(delta[1][l], 0xff, (size_t)Bp * ld[l] * 4)); } \
+        hipLaunchKernelGGL(kv, grid, dim3(RB_NT), ldsr, s, rb); \
+        compare("TUNE=" #T " vs middle4"); \
+        time_it("rowblock<static> TUNE=" #T, 500, [&]() { hipLaunchKernelGGL(kv, grid, dim3(RB_NT), ldsr, s, rb); }); \
+        stamps_of("TUNE=" #T, rowblock_kernel<RS, 0, 0, true, T>); \
+    } while (0)
+    time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
+    time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, rb); });
+    VARIANT(0);   // weights first (2 units), images of waves 4-7 deferred
+    VARIANT(32);  // + tail waves at priority 3
+    VARIANT(96);  // + slab waves too
+    time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
     return 0;
 }
