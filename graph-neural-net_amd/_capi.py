@@ -79,6 +79,7 @@ SYMBOLS = [
     ("gnn_mlp_specialization", C.c_int, [_H]),
     ("gnn_mlp_step_launches", C.c_int, [_H]),
     ("gnn_mlp_plan_note", C.c_char_p, [_H]),
+    ("gnn_mlp_rowblock_state", C.c_int, [_H]),
     ("gnn_mlp_timing_enable", C.c_int, [_H, C.c_int]),
     ("gnn_mlp_timing_read", C.c_int, [_H, C.c_int, _dp, C.POINTER(C.c_int64)]),
 ]

@@ -628,6 +628,7 @@ int gnn_mlp_specialize(gnn_mlp_t *h) { return guarded([&]() -> int {
 }); }
 int gnn_mlp_specialization(const gnn_mlp_t *h) { return h ? h->specialization : -1; }
 int gnn_mlp_step_launches(const gnn_mlp_t *h) { return !h ? -1 : h->chain ? 2 : h->mid4 ? 3 : 0; }
+int gnn_mlp_rowblock_state(const gnn_mlp_t *h) { return !h ? -1 : !h->rb ? 0 : h->rb_jit ? 3 : h->rb_static ? 2 : 1; }
 const char *gnn_mlp_plan_note(const gnn_mlp_t *h) { return h ? h->plan_note.c_str() : ""; }
 
 // ---- measurement ---------------------------------------------------------------------------

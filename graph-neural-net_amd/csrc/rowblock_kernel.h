@@ -333,6 +333,14 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     const int y_idx = p.row_idx ? (y_ix ? y_ld : 0) : row0 + y_r; // rows past the batch are masked below
     const f32x4 yv = *reinterpret_cast<const f32x4 *>((p.Y ? p.Y : p.slabs) + (y_on ? (size_t)y_idx * p.ldy + y_q * 4 : (size_t)0));
     if (Lm < 3 && y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv; // (no register product in front of the row tail)
+    // the weight units requested in phase 0 have landed in front of the slabs (or this wave has no slabs and nothing else to
+    // do until A_1 exists): their rows go to the LDS image NOW, in time the wave would spend waiting at the barrier
+    constexpr bool EARLY_IMG = (TUNE & 128) == 0;
+    if (EARLY_IMG && UPW1 > 0 && Lm >= 3) {
+#pragma unroll
+        for (int uu = 0; uu < UPW1; uu++)
+            if (uu < PF0 && uu < nu_1) to_image_1(uu);
+    }
     GNN_RB_WSTAMP(0); // this wave at the A_1 barrier
     __syncthreads();
     GNN_RB_STAMP(1);
@@ -385,7 +393,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                     for (int tt = 0; tt < 4; tt++)
 #pragma unroll
                         for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(av1[uu][tt], w1[uu][tt][j], acc[j], 0, 0, 0);
-                    if (!DEFER || wave < n_sum_waves) to_image_1(uu);
+                    if (!(EARLY_IMG && uu < PF0) && (!DEFER || wave < n_sum_waves)) to_image_1(uu);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -615,7 +623,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     else if (DEFER && UPW1 > 0 && Lm >= 3) {
 #pragma unroll
         for (int uu = 0; uu < UPW1; uu++)
-            if (uu < nu_1) to_image_1(uu);
+            if (!(EARLY_IMG && uu < PF0) && uu < nu_1) to_image_1(uu);
     }
     if (TUNE & 32) __builtin_amdgcn_s_setprio(0);
     GNN_RB_STAMP(4);  // wave 0's tail done

@@ -106,8 +106,12 @@ template <int GSRC> __device__ __forceinline__ float4 ts_gradient_in(const TileS
         if (STAMP && threadIdx.x == 0) p.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
-template <int GSRC, int GDST, bool FWD, bool STAMP = false>
-__global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p) {
+// NW: waves per workgroup, 8 or 4 (4: half the waves to dispatch for the same tiles -- the launch ramp of ~340 workgroups is
+// a measurable share of this kernel -- at the price of two row groups per wave in the forward product)
+template <int GSRC, int GDST, bool FWD, bool STAMP = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
+    constexpr int NT = NW * 64, RPW = 8 / NW; // threads; 16-row groups of a 128-row chunk per wave
+    static_assert(NW == 8 || NW == 4, "tile_step_kernel: 8 or 4 waves");
     constexpr int LDA = TS_TM + 16;  // gradient A image [k][m]: row stride = 16 (mod 32) floats
     constexpr int LDD = TS_TN;       // delta image [k][n]: 16 floats (lanes 16-31 land on banks 16-31)
     constexpr int LDW = TS_TN + 4;   // weight tile / partial tiles [m][n]
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     GNN_TS_STAMP_REAL(8);
     // ---- everything this block reads first, all loads in flight together ------------------------
     // gradient operands of the first K chunk
-    float4 va[4], vd;
+    float4 va[4 * RPW], vd[RPW];
     const int kc0 = (p.K < TS_KC) ? p.K : TS_KC;
     // A tile wholly inside its layer, a whole first chunk, rows in place: no bounds tests, no exec-mask branches -- every wave
     // runs this prologue before the first barrier, and a guarded 16-B load is ~13 instructions (see gemm_f32_kernel)
@@ -146,15 +150,19 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
                           (unsigned long long)TS_KC * (unsigned)(L.lda > L.ldd ? L.lda : L.ldd) < 0xffffffffull; // 32-bit offsets
     if (GSRC == 1 && interior) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = t + i * TS_THREADS, k = idx >> 4, q = idx & 15;
+        for (int i = 0; i < 4 * RPW; i++) {
+            const int idx = t + i * NT, k = idx >> 4, q = idx & 15;
             va[i] = *reinterpret_cast<const float4 *>(L.A + ((unsigned)k * (unsigned)L.lda + m0 + q * 4));
         }
-        vd = *reinterpret_cast<const float4 *>(L.D + ((unsigned)(t >> 2) * (unsigned)L.ldd + n0 + (t & 3) * 4));
+#pragma unroll
+        for (int i = 0; i < RPW; i++) {
+            const int idx = t + i * NT;
+            vd[i] = *reinterpret_cast<const float4 *>(L.D + ((unsigned)(idx >> 2) * (unsigned)L.ldd + n0 + (idx & 3) * 4));
+        }
     } else if (GSRC == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = t + i * TS_THREADS, k = idx >> 4, q = idx & 15;
+        for (int i = 0; i < 4 * RPW; i++) {
+            const int idx = t + i * NT, k = idx >> 4, q = idx & 15;
             va[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < kc0 && m0 + q * 4 < L.M) {
                 size_t a_row = (size_t)k;
@@ -163,10 +171,11 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
                 if (live) va[i] = *reinterpret_cast<const float4 *>(L.A + a_row * L.lda + m0 + q * 4);
             }
         }
-        {
-            const int k = t >> 2, q = t & 3;
-            vd = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < kc0) vd = *reinterpret_cast<const float4 *>(L.D + (size_t)k * L.ldd + n0 + q * 4);
+#pragma unroll
+        for (int i = 0; i < RPW; i++) {
+            const int idx = t + i * NT, k = idx >> 2, q = idx & 3;
+            vd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kc0) vd[i] = *reinterpret_cast<const float4 *>(L.D + (size_t)k * L.ldd + n0 + q * 4);
         }
     }
     float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f), v_old = w_old, g_in = w_old;
@@ -179,26 +188,33 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
     // the next batch's rows, already in MFMA fragment form: wave -> 16 batch rows of a 128-row chunk, lane
     // (fr, fq) -> row fr, inputs 16c + 4fq .. +3 of the tile (c = 0..3).  Straight to registers: A_0' is
     // k-contiguous, no wave shares another's rows, and the product below needs no LDS image of it.
-    f32x4 vn[4];
+    f32x4 vn[RPW][4];
     // a sampled next batch: this lane's row index of the first chunk is fetched NOW, so that the row loads, requested
     // ~3 000 cycles from here, do not start with a dependent round trip
-    int next_row0 = wave * 16 + fr;
-    if (fwd && p.next_idx && next_row0 < p.next_rows) next_row0 = p.next_idx[next_row0];
+    int next_row0[RPW];
+#pragma unroll
+    for (int g = 0; g < RPW; g++) {
+        next_row0[g] = (wave + g * NW) * 16 + fr;
+        if (fwd && p.next_idx && next_row0[g] < p.next_rows) next_row0[g] = p.next_idx[next_row0[g]];
+    }
     auto load_next = [&](int b0) {
-        const int b = b0 + wave * 16 + fr;
-        if (b0 == 0 && next_plain) { // (block-uniform)
-            const float *src = p.An + ((unsigned)b * (unsigned)p.ldan + m0 + 4 * fq);
 #pragma unroll
-            for (int c = 0; c < 4; c++) vn[c] = *reinterpret_cast<const f32x4 *>(src + c * 16);
-            return;
-        }
-        const bool live = b < p.next_rows;
-        const size_t row = live ? (b0 == 0 ? (size_t)next_row0 : p.next_idx ? (size_t)p.next_idx[b] : (size_t)b) : 0;
-        const float *src = p.An + row * p.ldan + m0 + 4 * fq;
+        for (int g = 0; g < RPW; g++) {
+            const int b = b0 + (wave + g * NW) * 16 + fr;
+            if (b0 == 0 && next_plain) { // (block-uniform)
+                const float *src = p.An + ((unsigned)b * (unsigned)p.ldan + m0 + 4 * fq);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            vn[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (live && m0 + c * 16 + 4 * fq < L.M) vn[c] = *reinterpret_cast<const f32x4 *>(src + c * 16);
+                for (int c = 0; c < 4; c++) vn[g][c] = *reinterpret_cast<const f32x4 *>(src + c * 16);
+                continue;
+            }
+            const bool live = b < p.next_rows;
+            const size_t row = live ? (b0 == 0 ? (size_t)next_row0[g] : p.next_idx ? (size_t)p.next_idx[b] : (size_t)b) : 0;
+            const float *src = p.An + row * p.ldan + m0 + 4 * fq;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                vn[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (live && m0 + c * 16 + 4 * fq < L.M) vn[g][c] = *reinterpret_cast<const f32x4 *>(src + c * 16);
+            }
         }
     };
     // (requested behind the gradient operands, below: it is needed ~2 500 cycles later, and in front of them it
@@ -217,8 +233,8 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
             if (k0) {
                 __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int idx = t + i * TS_THREADS, k = idx >> 4, q = idx & 15;
+                for (int i = 0; i < 4 * RPW; i++) {
+                    const int idx = t + i * NT, k = idx >> 4, q = idx & 15;
                     va[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (k < kc && m0 + q * 4 < L.M) {
                         size_t a_row = (size_t)(k0 + k);
@@ -227,16 +243,23 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
                         if (live) va[i] = *reinterpret_cast<const float4 *>(L.A + a_row * L.lda + m0 + q * 4);
                     }
                 }
-                const int k = t >> 2, q = t & 3;
-                vd = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < kc) vd = *reinterpret_cast<const float4 *>(L.D + (size_t)(k0 + k) * L.ldd + n0 + q * 4);
+#pragma unroll
+                for (int i = 0; i < RPW; i++) {
+                    const int idx = t + i * NT, k = idx >> 2, q = idx & 3;
+                    vd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < kc) vd[i] = *reinterpret_cast<const float4 *>(L.D + (size_t)(k0 + k) * L.ldd + n0 + q * 4);
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int idx = t + i * TS_THREADS, k = idx >> 4, q = idx & 15;
+            for (int i = 0; i < 4 * RPW; i++) {
+                const int idx = t + i * NT, k = idx >> 4, q = idx & 15;
                 *reinterpret_cast<float4 *>(&sA[k * LDA + q * 4]) = va[i];
             }
-            *reinterpret_cast<float4 *>(&sD[(t >> 2) * LDD + (t & 3) * 4]) = vd;
+#pragma unroll
+            for (int i = 0; i < RPW; i++) {
+                const int idx = t + i * NT;
+                *reinterpret_cast<float4 *>(&sD[(idx >> 2) * LDD + (idx & 3) * 4]) = vd[i];
+            }
             __syncthreads();
             if (k0 == 0) {
                 GNN_TS_STAMP(1);
@@ -300,25 +323,29 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_kernel(TileStepParams p)
         for (int j = 0; j < 4; j++) wv[c][j] = wcol[(c * 16 + j) * LDW];
     for (int b0 = 0; b0 < p.next_K; b0 += TS_KC) {
         if (b0) load_next(b0);
-        if (p.stage_out && tn == 0 && b0 + wave * 16 < p.next_K) { // (rows past the batch and columns past M are zeros in vn)
-            float *dst = p.stage_out + (size_t)(b0 + wave * 16 + fr) * p.ldan + m0 + 4 * fq;
 #pragma unroll
-            for (int c = 0; c < 4; c++)
-                if (m0 + c * 16 + 4 * fq < L.M) *reinterpret_cast<f32x4 *>(dst + c * 16) = vn[c];
-        }
-        if (b0 + wave * 16 < p.next_K) { // wave-uniform
-            f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < RPW; g++) {
+            const int wr = (wave + g * NW) * 16; // this wave's row group of the chunk
+            if (p.stage_out && tn == 0 && b0 + wr < p.next_K) { // (rows past the batch and columns past M are zeros in vn)
+                float *dst = p.stage_out + (size_t)(b0 + wr + fr) * p.ldan + m0 + 4 * fq;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (c & 1) z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][j], vn[c][j], z1, 0, 0, 0);
-                    else z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][j], vn[c][j], z0, 0, 0, 0);
-                }
+                for (int c = 0; c < 4; c++)
+                    if (m0 + c * 16 + 4 * fq < L.M) *reinterpret_cast<f32x4 *>(dst + c * 16) = vn[g][c];
             }
-            const f32x4 z = z0 + z1; // rows n = 4*fq + r, column b = fr
-            GNN_TS_STAMP(5);
-            *reinterpret_cast<f32x4 *>(slab + (size_t)(b0 + wave * 16 + fr) * p.ldz + n0 + 4 * fq) = z;
+            if (b0 + wr < p.next_K) { // wave-uniform
+                f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (c & 1) z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][j], vn[g][c][j], z1, 0, 0, 0);
+                        else z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][j], vn[g][c][j], z0, 0, 0, 0);
+                    }
+                }
+                const f32x4 z = z0 + z1; // rows n = 4*fq + r, column b = fr
+                GNN_TS_STAMP(5);
+                *reinterpret_cast<f32x4 *>(slab + (size_t)(b0 + wr + fr) * p.ldz + n0 + 4 * fq) = z;
+            }
         }
     }
     GNN_TS_STAMP(6);

@@ -287,6 +287,11 @@ class NeuralNet:
         return self._lib.gnn_mlp_step_launches(self._h)
 
     @property
+    def rowblock_state(self):
+        """The two-launch step's training kernel: 0 middle4_kernel, 1 rowblock runtime shape, 2 prebuilt, 3 instantiated at run time."""
+        return self._lib.gnn_mlp_rowblock_state(self._h)
+
+    @property
     def plan_note(self):
         """Why the net is not on the two-launch path ('' when it is)."""
         s = self._lib.gnn_mlp_plan_note(self._h)

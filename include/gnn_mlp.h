@@ -269,6 +269,10 @@ int gnn_mlp_specialization(const gnn_mlp_t *h);
  * (row-block kernel + tile-owner kernel, csrc/tile_step_kernel.h), 3 = first layer / row-block kernel /
  * gradient+update, 0 = per-layer GEMMs (the count then depends on the layer count). */
 int gnn_mlp_step_launches(const gnn_mlp_t *h);
+/* The row-block kernel of the two-launch TRAINING step (csrc/rowblock_kernel.h): 0 = not taken (bf16, a plan that does not
+ * fit, GNN_MLP_ROWBLOCK=0: the step then uses middle4_kernel), 1 = runtime-shape instantiation, 2 = prebuilt for the shape,
+ * 3 = instantiated at run time for the shape (gnn_mlp_specialize / the 16th step). */
+int gnn_mlp_rowblock_state(const gnn_mlp_t *h);
 /* Why gnn_mlp_step_launches() is not 2 for this net ("" when it is): the decision gnn_mlp_create took (layer count,
  * LDS budget, slab count, a failed allocation, a GNN_MLP_* development switch).  The string lives as long as the handle. */
 const char *gnn_mlp_plan_note(const gnn_mlp_t *h);

@@ -368,6 +368,43 @@ def test_graph_replayed_steps_equal_eager(gnn):
     assert np.array_equal(wa, wb)     # same kernels, same order: bitwise
 
 
+@pytest.mark.parametrize("dims,B,inner", [([784, 300, 100, 10], 128, LEAKY), ([784, 100, 50, 10], 32, LEAKY),
+                                          ([100, 64, 48, 32, 10], 40, SIGMOID), ([60, 50, 40, 30, 20, 10], 33, TANH), ([300, 40, 10], 17, RELU)])
+def test_rowblock_kernel_against_middle4_and_oracle(gnn, oracle_mod, monkeypatch, dims, B, inner):
+    """The two-launch step's training kernel (csrc/rowblock_kernel.h: weights streamed into the multiplying wave's
+    registers, K slices in slice order) against round 2's form of the same step (GNN_MLP_ROWBLOCK=0: middle4_kernel with
+    the LDS-staged weights) -- same mathematics, another summation order of the middle products -- and against the oracle:
+    nets of 3 to 6 layers, every activation family, ragged batches."""
+    import os
+    if os.environ.get("GNN_MLP_PATH") or os.environ.get("GNN_MLP_CHAIN") == "0" or os.environ.get("GNN_MLP_ROWBLOCK") == "0":
+        pytest.skip("path forced by the environment")
+    nb, n = 3, 6
+    X, Y = make_batch(dims, B * nb, seed=71, sparse=True)
+    new = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    monkeypatch.setenv("GNN_MLP_ROWBLOCK", "0")
+    old = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    monkeypatch.delenv("GNN_MLP_ROWBLOCK")
+    assert new.step_launches == 2 and old.step_launches == 2
+    assert new.rowblock_state in (1, 2) and old.rowblock_state == 0
+    ref = oracle_mod.OracleNet(dims, inner_act=inner)
+    ref.set_alloc_per_sample(0)
+    new.upload_dataset(X, Y); old.upload_dataset(X, Y)
+    new.train_range(0, B, n, 0.0125, 0.9)
+    old.train_range(0, B, n, 0.0125, 0.9)
+    for s in range(n):
+        ref.gradient_step(X[(s % nb) * B:(s % nb + 1) * B], Y[(s % nb) * B:(s % nb + 1) * B], 0.0125, 0.9)
+    assert np.abs(new.get_weights() - old.get_weights()).max() <= 2e-6
+    assert np.abs(new.get_weights() - ref.get_weights()).max() <= n * W_ATOL
+    # one gradient on a fresh batch, element by element
+    g = new.calculateWeightGradient(X[:B], Y[:B])
+    gr = sum(ref.calculate_weight_gradient(X[b], Y[b]) for b in range(B))
+    off = 0
+    for l in range(len(dims) - 1):
+        k = dims[l] * dims[l + 1]
+        grl = gr[off:off + k].reshape(dims[l], dims[l + 1]); off += k
+        assert np.abs(g[l] - grl).max() <= 3e-5 * np.abs(grl).max() + 1e-9, "layer %d" % l
+
+
 def test_graph_replay_between_eager_steps_with_hints(gnn):
     """A captured step sequence must not depend on what ran before it, nor leave the handle believing in work the device
     does not hold (two-launch path: the first-layer sums made AHEAD for the next batch).  bench.py's shape: a warm run
@@ -728,7 +765,9 @@ def test_runtime_specialisation_is_bitwise_identical(gnn):
     a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
     b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
     assert a.specialization == 0 and b.specialization == 0
+    assert a.rowblock_state == 1                       # the training row-block kernel, runtime-shape instantiation
     assert b.specialize() == 2, "run-time instantiation failed (hiprtc unavailable?)"
+    assert b.rowblock_state == 3                       # ... and its hiprtc instantiation for this shape
     a.upload_dataset(X, Y); b.upload_dataset(X, Y)
     for s in range(6):
         a.gradient_step_range((s % nb) * B, B, 0.0125, 0.9)
@@ -738,6 +777,6 @@ def test_runtime_specialisation_is_bitwise_identical(gnn):
     assert np.array_equal(a.argmax_range(0, B), b.argmax_range(0, B))
     # the two shapes BASELINE.json names are prebuilt; a long training call specialises by itself
     c = gnn.SoftmaxCrossEntropyNeuralNet([784, 300, 100, 10], max_batch=128)
-    assert c.specialization == 1
+    assert c.specialization == 1 and c.rowblock_state == 2
     a.train_range(0, B, 64, 0.0125, 0.9)
     assert a.specialization == 2

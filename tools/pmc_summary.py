@@ -29,7 +29,7 @@ def main():
                    "hits included): each XCD's L2 starts cold every kernel, so panels shared by tiles on different XCDs "
                    "are fetched once per XCD.", "kernels": {}}
     for k in fetch:
-        if "gnn::" not in k or k not in write or not any(w in k for w in ("fwd_first", "middle4", "grad_update", "tile_step")):
+        if "gnn::" not in k or k not in write or not any(w in k for w in ("fwd_first", "middle4", "rowblock", "grad_update", "tile_step")):
             continue
         f, w = fetch[k] / nf[k], write[k] / nw[k]
         out["kernels"][k] = {"FETCH_SIZE": f, "launches_FETCH_SIZE": nf[k], "WRITE_SIZE": w, "launches_WRITE_SIZE": nw[k],

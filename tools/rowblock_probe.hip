@@ -117,8 +117,7 @@ int main(int argc, char **argv) {
     time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
     time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, rb); });
     VARIANT(0);   // weights first (2 units), images of waves 4-7 deferred
-    VARIANT(32);  // + tail waves at priority 3
-    VARIANT(96);  // + slab waves too
+    VARIANT(128); // image rows of the first units NOT copied before the A_1 barrier
     time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
     return 0;
 }

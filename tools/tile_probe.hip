@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 using namespace gnn;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -49,10 +50,26 @@ int main(int argc, char **argv) {
         printf("%-44s %8.2f us per call\n", name, ms * 1000.f / n);
     };
     time_it("tile_step<grad, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<grad, update, fwd> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
+    time_it("tile_step<grad, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<grad, update, fwd> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
+    time_it("tile_step<grad, store G> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 1, false, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
+    time_it("tile_step<fwd only> 4 waves", 500, [&]() { TileStepParams u = t; u.n_layers = 1; hipLaunchKernelGGL((tile_step_kernel<0, 0, true, false, 4>), dim3(tiles0), dim3(256), 0, s, u); });
     time_it("tile_step<grad, update>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, false>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<grad, store G>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 1, false>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<G, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<2, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<fwd only> (layer 0 tiles)", 500, [&]() { TileStepParams u = t; u.n_layers = 1; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
+    {   // 4 waves against 8: the forward-only launch leaves W alone, so its slabs must agree bit for bit
+        std::vector<float> s8((size_t)ns * Bp * ld[1]), s4(s8.size());
+        TileStepParams u = t; u.n_layers = 1;
+        hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u);
+        CK(hipStreamSynchronize(s)); CK(hipMemcpy(s8.data(), slabs, s8.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(slabs, 0xff, s8.size() * 4));
+        hipLaunchKernelGGL((tile_step_kernel<0, 0, true, false, 4>), dim3(tiles0), dim3(256), 0, s, u);
+        CK(hipStreamSynchronize(s)); CK(hipMemcpy(s4.data(), slabs, s4.size() * 4, hipMemcpyDeviceToHost));
+        size_t bad = 0; for (size_t i = 0; i < s8.size(); i++) bad += memcmp(&s8[i], &s4[i], 4) != 0;
+        printf("forward-only slabs, 4 waves vs 8: %zu of %zu words differ\n", bad, s8.size());
+    }
     CK(hipMemsetAsync(stamps, 0, 4096 * 16 * 8, s));
     hipLaunchKernelGGL((tile_step_kernel<1, 2, true, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t);
     CK(hipStreamSynchronize(s));
