@@ -70,6 +70,15 @@ struct TileStepParams {
     const float *Gpeer[TS_MAX_PEERS]; int n_peer; const float *Gself; unsigned slice;
 };
 
+// 16-B store that is written THROUGH the XCD's L2 (sc1): the line does not stay dirty, so the end of the kernel has nothing
+// to write back for it (a kernel boundary costs ~B / 6 TB/s for B dirty bytes, MI355X_MICROARCH.md, row `boundary`), and the
+// bytes leave while the kernel still runs.  Inline asm (the compiler has no spelling for it on a 16-B vector); the s_nop
+// covers the store-data hazard the compiler cannot see.  WT = false: a plain store.
+template <bool WT> __device__ __forceinline__ void ts_store16(float *dst, f32x4 v) {
+    if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+    else *reinterpret_cast<f32x4 *>(dst) = v;
+}
+
 // the gradient tile's 16 B of this lane when it does not come from this launch's own product
 template <int GSRC> __device__ __forceinline__ float4 ts_gradient_in(const TileStepParams &p, const GradLayer &L, size_t e_off, bool e_ok) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -108,7 +117,8 @@ template <int GSRC> __device__ __forceinline__ float4 ts_gradient_in(const TileS
 
 // NW: waves per workgroup, 8 or 4 (4: half the waves to dispatch for the same tiles -- the launch ramp of ~340 workgroups is
 // a measurable share of this kernel -- at the price of two row groups per wave in the forward product)
-template <int GSRC, int GDST, bool FWD, bool STAMP = false, int NW = 8>
+// WT: 1 = the slabs, 2 = the masters too are stored write-through (ts_store16)
+template <int GSRC, int GDST, bool FWD, bool STAMP = false, int NW = 8, int WT = 2>
 __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
     constexpr int NT = NW * 64, RPW = 8 / NW; // threads; 16-row groups of a 128-row chunk per wave
     static_assert(NW == 8 || NW == 4, "tile_step_kernel: 8 or 4 waves");
@@ -300,8 +310,8 @@ __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
         adj.w = sgd_adj(p.step_over_b, g.w, p.momentum, v_old.w);
         w_new = make_float4(w_old.x - adj.x, w_old.y - adj.y, w_old.z - adj.z, w_old.w - adj.w);
         if (e_ok) {
-            *reinterpret_cast<float4 *>(L.W + e_off) = w_new;
-            *reinterpret_cast<float4 *>(L.V + e_off) = adj;
+            ts_store16<(WT >= 2)>(L.W + e_off, (f32x4){w_new.x, w_new.y, w_new.z, w_new.w});
+            ts_store16<(WT >= 2)>(L.V + e_off, (f32x4){adj.x, adj.y, adj.z, adj.w});
         }
     }
     GNN_TS_STAMP(3);
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
                 }
                 const f32x4 z = z0 + z1; // rows n = 4*fq + r, column b = fr
                 GNN_TS_STAMP(5);
-                *reinterpret_cast<f32x4 *>(slab + (size_t)(b0 + wr + fr) * p.ldz + n0 + 4 * fq) = z;
+                ts_store16<(WT >= 1)>(slab + (size_t)(b0 + wr + fr) * p.ldz + n0 + 4 * fq, z);
             }
         }
     }
@@ -472,8 +482,8 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
         adj.w = sgd_adj(p.step_over_b, g.w, p.momentum, v_old.w);
         w_new = make_float4(w_old.x - adj.x, w_old.y - adj.y, w_old.z - adj.z, w_old.w - adj.w);
         if (e_ok) {
-            *reinterpret_cast<float4 *>(L.W + e_off) = w_new;
-            *reinterpret_cast<float4 *>(L.V + e_off) = adj;
+            ts_store16<true>(L.W + e_off, (f32x4){w_new.x, w_new.y, w_new.z, w_new.w}); // (write-through: see ts_store16)
+            ts_store16<true>(L.V + e_off, (f32x4){adj.x, adj.y, adj.z, adj.w});
             *reinterpret_cast<bf16x4 *>(p.Wb[li] + e_off) = (bf16x4){(__bf16)w_new.x, (__bf16)w_new.y, (__bf16)w_new.z, (__bf16)w_new.w};
         }
     }
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, join8(vn[0][0], vn[0][1]), z, 0, 0, 0);
             z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, join8(vn[1][0], vn[1][1]), z, 0, 0, 0);
-            *reinterpret_cast<f32x4 *>(slab + (size_t)(b0 + wave * 16 + fr) * p.ldz + n0 + 4 * fg) = z; // rows n = 4fg + r, column b = fr
+            ts_store16<true>(slab + (size_t)(b0 + wave * 16 + fr) * p.ldz + n0 + 4 * fg, z); // rows n = 4fg + r, column b = fr
         }
     }
 }

@@ -49,9 +49,17 @@ int main(int argc, char **argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-44s %8.2f us per call\n", name, ms * 1000.f / n);
     };
-    time_it("tile_step<grad, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<grad, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 0>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<grad, update, fwd> slabs write-through", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 1>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<grad, update, fwd> slabs + W, V write-through", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<grad, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 0>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<grad, update, fwd> slabs write-through", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 1>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    time_it("tile_step<grad, update, fwd> slabs + W, V write-through", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    {   // a pair as in a real step: the tile kernel followed by a dependent small kernel (what the next launch waits for)
+        time_it("pair: tile_step + dependent fwd-only launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
+        time_it("pair: tile_step (write-through 2) + dependent launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
+    }
     time_it("tile_step<grad, update, fwd> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
-    time_it("tile_step<grad, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<grad, update, fwd> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
     time_it("tile_step<grad, store G> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 1, false, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
     time_it("tile_step<fwd only> 4 waves", 500, [&]() { TileStepParams u = t; u.n_layers = 1; hipLaunchKernelGGL((tile_step_kernel<0, 0, true, false, 4>), dim3(tiles0), dim3(256), 0, s, u); });
