@@ -136,7 +136,10 @@ __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
 #pragma unroll
     for (int i = 1; i < MAX_LAYERS; i++)
         if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].block_begin) li = i;
-    const GradLayer L = p.layer[li]; // by value: one batch of scalar loads, not one round trip per field as it is first used
+    // by value: one batch of scalar loads, not one round trip per field as it is first used; layer 0's descriptor (nine of
+    // ten workgroups) is requested at once, beside the block_begin fields that decide li, not behind them
+    GradLayer L = p.layer[0];
+    if (li != 0) L = p.layer[li];
     int tm, tn;
     if (!L.tiling.tile_of(blockIdx.x - L.block_begin, tm, tn)) return;
     const int m0 = tm * TS_TM, n0 = tn * TS_TN;
@@ -385,7 +388,10 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
 #pragma unroll
     for (int i = 1; i < MAX_LAYERS; i++)
         if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].block_begin) li = i;
-    const GradLayer L = p.layer[li]; // by value: one batch of scalar loads, not one round trip per field as it is first used
+    // by value: one batch of scalar loads, not one round trip per field as it is first used; layer 0's descriptor (nine of
+    // ten workgroups) is requested at once, beside the block_begin fields that decide li, not behind them
+    GradLayer L = p.layer[0];
+    if (li != 0) L = p.layer[li];
     int tm, tn;
     if (!L.tiling.tile_of(blockIdx.x - L.block_begin, tm, tn)) return;
     const int m0 = tm * TS_TM, n0 = tn * TS_TN;
