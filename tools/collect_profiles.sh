@@ -12,6 +12,25 @@ cp "$SRC/stats_cfg45_bf16/run_kernel_stats.csv" "$DST/final_configs45_bf16_kerne
 python3 tools/pmc_summary.py "$SRC/pmc_fetch/run_counter_collection.csv" "$SRC/pmc_write/run_counter_collection.csv" > "$DST/pmc_traffic.json"
 python3 tools/sq_summary.py "$SRC/pmc_sq/run_counter_collection.csv" > "$DST/sq_counters.json"
 python3 tools/mfma_summary.py "$SRC/pmc_mfma/run_counter_collection.csv" "$SRC/pmc_mfma_cfg45/run_counter_collection.csv" > "$DST/mfma_counters.json"
+for c in 4 5; do for d in f32 bf16; do
+  n=$(python3 - "$SRC/trace_cfg${c}_$d/run_kernel_trace.csv" <<'PY'
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+names = [r["Kernel_Name"] for r in rows][-400:]
+# the period of the dispatch sequence = launches per step
+for p in range(3, 60):
+    if all(names[-1 - i] == names[-1 - i - p] for i in range(2 * p)):
+        print(p); break
+else:
+    print(16)
+PY
+)
+  { echo "== config key $c, $d: the last two steps' dispatches ($n launches per step; under the profiler)"; python3 tools/step_trace.py "$SRC/trace_cfg${c}_$d/run_kernel_trace.csv" $((2 * n)); } >> "$DST/final_step_trace_configs45.txt"
+done; done
+cp "$SRC/rowblock_probe.log" "$DST/rowblock_probe_final.log"
+cp "$SRC/tile_probe.log" "$DST/tile_probe_final.log"
+cp "$SRC/config5_hybrid_choices.jsonl" "$DST/config5_hybrid_choices.jsonl"
+for r in direct direct_rs; do cp "$SRC/bench_library_8_shared_$r.json" "$DST/bench_library_8_replicas_sharing_one_gpu_$r.json"; cp "$SRC/bench_library_8_shared_${r}_bf16.json" "$DST/bench_library_8_replicas_sharing_one_gpu_${r}_bf16.json"; done
 cp "$SRC/bench_default.json"      "$DST/final_bench_f32.json"
 cp "$SRC/bench_bf16.json"         "$DST/final_bench_bf16.json"
 cp "$SRC/bench_dp1_graph.json"    "$DST/final_bench_dp_path_n1_graph.json"

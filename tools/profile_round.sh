@@ -24,6 +24,10 @@ run pmc_mfma    --kernel-trace --pmc $MF --output-format csv -d "$ROOT/$OUT/pmc_
 run pmc_mfma_cfg45 --kernel-trace --pmc $MF --output-format csv -d "$ROOT/$OUT/pmc_mfma_cfg45" -o run -- python3 $ROOT/tools/bench_configs.py 4 5 f32 bf16 --steps 24
 run stats_cfg45_f32  --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_cfg45_f32"  -o run -- python3 $ROOT/tools/bench_configs.py 4 5 f32 --steps 60
 run stats_cfg45_bf16 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_cfg45_bf16" -o run -- python3 $ROOT/tools/bench_configs.py 4 5 bf16 --steps 60
+# one config per trace, for the per-step dispatch lists (tools/step_trace.py wants the tail of ONE timed loop)
+for c in 4 5; do for d in f32 bf16; do
+run trace_cfg${c}_$d --kernel-trace --output-format csv -d "$ROOT/$OUT/trace_cfg${c}_$d" -o run -- python3 $ROOT/tools/bench_configs.py $c $d --steps 40
+done; done
 cd "$ROOT"
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python3 bench.py --dtype bf16 --no-cpu-baseline --no-other-configs > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"
@@ -31,5 +35,13 @@ python3 bench.py --dp-path --no-cpu-baseline --no-other-configs --steps 2048 --w
 GNN_MLP_CHAIN=0 python3 bench.py --no-cpu-baseline --no-other-configs > "$OUT/bench_three_launch.json" 2> "$OUT/bench_three_launch.err"
 python3 tools/bench_configs.py 1 2 4 5 f32 bf16 --graph > "$OUT/configs_all.jsonl" 2> "$OUT/configs_all.err"
 python3 tools/bench_host_path.py > "$OUT/host_path.txt" 2>&1
+# the in-library data-parallel handle, replicas sharing this one GPU (a rehearsal of the control flow, not a scaling number)
+for r in direct direct_rs; do
+python3 bench.py --gpus 8 --dp-impl library --dp-reducer $r --share-gpu --no-cpu-baseline --steps 512 --warmup 128 > "$OUT/bench_library_8_shared_$r.json" 2> "$OUT/bench_library_8_shared_$r.err"
+python3 bench.py --gpus 8 --dp-impl library --dp-reducer $r --share-gpu --no-cpu-baseline --steps 512 --warmup 128 --dtype bf16 > "$OUT/bench_library_8_shared_${r}_bf16.json" 2>> "$OUT/bench_library_8_shared_$r.err"
+done
+tools/rowblock_probe > "$OUT/rowblock_probe.log" 2>&1
+tools/tile_probe > "$OUT/tile_probe.log" 2>&1
+for m in 0 1 2 3; do echo "GNN_MLP_HYBRID=$m"; GNN_MLP_HYBRID=$m python3 tools/bench_configs.py 5 f32 --steps 200 2>/dev/null; done > "$OUT/config5_hybrid_choices.jsonl"
 python3 tools/bench_trainer.py > "$OUT/trainer.txt" 2>&1
 ls -R "$OUT" | head -80
