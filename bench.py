@@ -20,9 +20,9 @@ line and returns the worst exit code.
 Graph or eager (data-parallel path) is decided BEFORE anything runs: `--dp-mode graph` captures
 one pass over the resident batches -- kernels and the RCCL all-reduce -- into one HIP graph.  If
 that capture does not produce a graph, the stream it ran on stays invalidated, and a process that
-holds an RCCL process group then dies within ~100 ms: torch's ProcessGroupNCCL watchdog thread
-polls the end event of the collective it enqueued on that stream (hipEventQuery ->
-c10_hip_check -> uncaught c10::Error -> abort; this is the round-1 "later HIP calls crashed").
+holds an RCCL process group then dies within ~100 ms (the round-1 "later HIP calls crashed").  The
+suspected cause -- not evidenced by a kept log -- is torch's ProcessGroupNCCL watchdog thread polling the
+end event of the collective it enqueued on that stream.
 So a rank whose capture failed reports it through a CPU-side store and leaves AT ONCE with
 EXIT_CAPTURE_FAILED, its peers follow, and the eager run happens in FRESH processes: a process that
 never touches the GPU supervises the attempt(s) -- the launcher for a group it started itself, a
@@ -425,7 +425,7 @@ def worker(args, argv):
                 print("rank %d: hipGraph capture failed (%s: %s)" % (rank, type(e).__name__,
                                                                      (str(e).splitlines() or [""])[0]), file=sys.stderr)
             if not ok:
-                # The stream is invalidated and the RCCL watchdog is about to find out: tell the peers and
+                # The stream is invalidated and this process is about to die (suspected: the RCCL watchdog): tell the peers and
                 # leave at once -- no further GPU call, no teardown, no waiting.
                 try:
                     if store is not None:
@@ -586,7 +586,7 @@ def worker(args, argv):
                         "other": {names[k]: entry(k) for k in kernels if k != dom}}
         if dist is None:
             # PCIe-inclusive rate of the literal NeuralNet.gradientStep(double[] rows) call shape: fp64 host
-            # batch -> pageable H2D -> convert -> step.  Reported beside `value`, never as `value`.
+            # batch -> f32 in a pinned slot -> staging kernel reading it over PCIe -> step.  Reported beside `value`, never as `value`.
             nh = 200
             for s in range(20):
                 net.gradientStep(X[:BATCH], STEP, MOMENTUM, False, expected=Y[:BATCH])
