@@ -155,6 +155,14 @@ __device__ __forceinline__ float rb_sum32(float x) {
     return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
 }
 
+// x + (x of the lane 16 away, lane ^ 16): rows 1 and 3 of one copy change places with rows 0 and 2 of the other
+__device__ __forceinline__ float rb_sum16(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned lo = r[0], hi = r[1];
+    return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
+}
+
 // Two tasks of the backward product (delta . W^T from the LDS image, see rowblock_product<true>) interleaved in ONE wave:
 // four independent accumulator chains and the reads of both tasks in flight together -- a lone task is a chain of
 // read - wait - 16 dependent MFMAs per trip, and a wave ran its two tasks one after the other.
@@ -293,6 +301,8 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     // the first-layer K slabs: one float4 of the four A_1 rows per thread, all slabs of it; slab order; then f.
     // Rows past the batch and columns past d_1 are zeros (f(0) != 0 for the sigmoid).
     const int q1 = m.ld[1] >> 2;
+    f32x4 a1v = {0.f, 0.f, 0.f, 0.f}; // this thread's float4 of A_1 and where the tile kernel reads it (stored below, see there)
+    unsigned a1_goff = 0xffffffffu;
     if (wave * 64 < 4 * q1) { // (wave-uniform)
         if (TUNE & 64) { if (wave >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); } // the slab waves over the others; the younger one of a SIMD first
         const bool a1_on = t < 4 * q1;
@@ -317,7 +327,8 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         for (int j = 0; j < 4; j++) a[j] = (lrow && a1_q * 4 + j < m.d[1]) ? act_fn(ACT, z[j]) : 0.f;
         if (a1_on) {
             *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a;
-            *reinterpret_cast<f32x4 *>(p.act[1] + (size_t)(row0 + a1_r) * m.ld[1] + a1_q * 4) = a; // the tile kernel reads A_1
+            a1v = a;
+            a1_goff = (unsigned)(row0 + a1_r) * (unsigned)m.ld[1] + (unsigned)(a1_q * 4);
         }
         if (TUNE & 64) __builtin_amdgcn_s_setprio(0);
     }
@@ -341,6 +352,10 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         for (int uu = 0; uu < UPW1; uu++)
             if (uu < PF0 && uu < nu_1) to_image_1(uu);
     }
+    // A_1 for the tile kernel: stored LAST.  The memory counter counts stores too, and the copies above wait for "all but
+    // the youngest request" (what a wave without slabs needs): with the store in front of them the slab waves sat out its
+    // round trip to L2 in front of the barrier.
+    if (a1_goff != 0xffffffffu) *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(p.act[1]) + (size_t)(a1_goff * 4u)) = a1v;
     GNN_RB_WSTAMP(0); // this wave at the A_1 barrier
     __syncthreads();
     GNN_RB_STAMP(1);
@@ -453,7 +468,12 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     // A lone wave hides no latency, so the chain is kept short: lane (kg = lane / 4, q = lane % 4) multiplies rows
     // k = kg, kg + 16, .. of the last weight image with the float4 of columns 4q..4q+3 -- every LDS read of the logits is in
     // flight at once (<= 8 + 8 reads instead of 25 dependent rounds of two), the 16 k groups meet by two DPP rotations and
-    // two lane exchanges, and the output rule runs on the quad (q = 0..3 holds the 16 padded classes).
+    // two row swaps, and the output rule runs on the quad (q = 0..3 holds the 16 padded classes).
+    // Every load of this wave was issued thousands of cycles ago, but the clamped weight units a wave does not multiply are
+    // never waited for, so the compiler still counts them as pending: it then guards the first reuse of their registers with
+    // s_waitcnt vmcnt(0..3) -- AFTER the stores below, which the same counter counts, so the wave sat out a store's round
+    // trip to L2 three times (logits, delta_{L-2}, the backward product's start).  Waiting here costs nothing and clears it.
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only (expcnt, lgkmcnt: no wait)
     if (wave < 4) {
         if (TUNE & 32) __builtin_amdgcn_s_setprio(3); // the four waves on the critical path, over the image copies of the other four
         const int r = wave, row = row0 + r;
@@ -469,7 +489,9 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                 for (int j = 0; j < 4; j++) v[j] = (row < p.B && n + j < m.d[l + 1]) ? act_fn(ACT, v[j]) : 0.f;
                 *reinterpret_cast<f32x4 *>(p.act[l + 1] + (size_t)row * N + n) = v;
                 *reinterpret_cast<f32x4 *>(smem + m.off_act[l + 1] + r * (N + 4) + n) = v; // (read back below by this very wave)
+                if (STAMP) asm volatile("" : "+v"(v));
             }
+            GNN_RB_STAMP(3); // this row's slices summed
         }
         const float *a = smem + m.off_act[Lm - 1] + r * (ldp + 4);
         const float *Wl = smem + m.off_w[Lm - 1];
@@ -496,8 +518,8 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
             float v = z4[j];
             v += dpp_f<0x128>(v);  // row_ror:8
             v += dpp_f<0x124>(v);  // row_ror:4
-            v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __builtin_bit_cast(int, v)));
-            v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
+            v = rb_sum16(v);       // lane ^ 16, lane ^ 32: register swaps (a ds_bpermute pair per value was two more
+            v = rb_sum32(v);       // LDS round trips on this chain)
             z4[j] = v;
         }
         if (STAMP) { asm volatile("" : "+v"(z4)); GNN_RB_STAMP(10); } // k groups reduced
@@ -601,6 +623,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                 for (int qq = 0; qq < 4; qq++) wn[half][qq] = *reinterpret_cast<const f32x4 *>(Wl + ((on && 4 * qq < m.kr[Lm]) ? n * lwl + 4 * qq : 0));
                 an[half] = a[n < ldp ? n : 0];
             }
+            if (STAMP) { asm volatile("" : "+v"(wn[1][3]), "+v"(an[1])); GNN_RB_STAMP(5); } // delta_{L-2}'s operands read
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const int n = lane + 64 * half;
@@ -679,6 +702,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         if (l > 1) __syncthreads();
         GNN_RB_STAMP(13);
     }
+    GNN_RB_WSTAMP(4); // this wave done
     GNN_RB_STAMP(14);
 }
 

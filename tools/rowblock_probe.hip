@@ -90,15 +90,16 @@ int main(int argc, char **argv) {
         CK(hipMemsetAsync(stamps, 0, 4096 * 16 * 8, s));
         hipLaunchKernelGGL(kst, grid, dim3(RB_NT), ldsr, s, rb);
         CK(hipStreamSynchronize(s));
-        std::vector<unsigned long long> hs((size_t)32 * 16 * 5);
+        std::vector<unsigned long long> hs((size_t)32 * 16 * 6);
         CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
         for (int w : {0, 16}) {
             const unsigned long long *q = &hs[w * 16];
-            printf("%s wg%-2d: slabs->A1 %llu (wave 0: loads issued +%llu, slabs in +%llu) | L2 product %llu (wave 0 done +%llu) | L2 reduce %llu | row tail %llu | backward %llu | total %llu cycles\n", name, w,
-                   q[1] - q[0], q[6] - q[0], q[7] - q[0], q[2] - q[1], q[8] - q[1], q[3] - q[2], q[12] - q[3], q[14] - q[12], q[14] - q[0]);
-            printf("    tail of wave 0 (from the reduce barrier): logits +%llu | k groups reduced +%llu | output rule +%llu | stores + delta_{L-2} +%llu\n", q[9] - q[3], q[10] - q[3], q[11] - q[3], q[4] - q[3]);
-            const char *rn[4] = {"at A1 barrier", "MFMAs done", "at partial barrier", "tail phase end"};
-            for (int r = 0; r < 4; r++) {
+            printf("%s wg%-2d: slabs->A1 %llu (wave 0: loads issued +%llu, slabs in +%llu) | L2 product %llu (wave 0 done +%llu) | row tail %llu | backward %llu | total %llu cycles\n", name, w,
+                   q[1] - q[0], q[6] - q[0], q[7] - q[0], q[2] - q[1], q[8] - q[1], q[12] - q[2], q[14] - q[12], q[14] - q[0]);
+            printf("    tail of wave 0 (from the partial-tile barrier): slices summed +%llu | logits +%llu | k groups reduced +%llu | output rule +%llu | delta_{L-2} operands read +%llu | done +%llu\n",
+                   q[3] - q[2], q[9] - q[2], q[10] - q[2], q[11] - q[2], q[5] - q[2], q[4] - q[2]);
+            const char *rn[5] = {"at A1 barrier", "MFMAs done", "at partial barrier", "tail phase end", "done"};
+            for (int r = 0; r < 5; r++) {
                 printf("    waves %-18s (from start):", rn[r]);
                 for (int v = 0; v < 8; v++) printf(" %6lld", (long long)(hs[(size_t)(16 * 32) * (1 + r) + w * 16 + v] - q[0]));
                 printf("\n");
