@@ -231,7 +231,7 @@ int gnn_mlp_destroy(gnn_mlp_t *h) { return guarded([&]() -> int {
     for (float *p : h->act) fr(p);
     for (float *p : h->delta) fr(p);
     fr(h->logits); fr(h->prob); fr(h->ybuf); fr(h->lossv); fr(h->labels); fr(h->idxbuf);
-    fr(h->stage_out); release_host_staging(h); fr(h->DX); fr(h->DY); fr(h->slabs);
+    fr(h->stage_out); release_host_staging(h); fr(h->DX); fr(h->DY); fr(h->slabs); fr(h->ts_map); fr(h->ts_map0);
     fr(h->Wb); fr(h->DXb);
     for (int i = 0; i < 2; i++) { fr(h->xstage[i]); fr(h->xstage_b[i]); }
     for (__bf16 *p : h->actb) fr(p);

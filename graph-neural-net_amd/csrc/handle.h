@@ -86,6 +86,7 @@ struct gnn_mlp {
     bool chain = false;
     gnn::TileStepParams tsp{};
     int ts_tiles = 0, ts_tiles0 = 0; // blocks of all layers / of layer 0 alone
+    uint32_t *ts_map = nullptr, *ts_map0 = nullptr; // workgroup -> tile of the two grids (make_tile_map), device memory
     float *slabs = nullptr;
     int n_slabs = 0;
     std::string plan_note;    // why the net is NOT on the two-launch path (empty when it is): gnn_mlp_plan_note

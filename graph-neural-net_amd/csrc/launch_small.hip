@@ -256,6 +256,7 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
     const bool fwd_only = gsrc == 0;
     const dim3 grid(fwd_only ? h->ts_tiles0 : h->ts_tiles), block(TS_THREADS);
     if (fwd_only) t.n_layers = 1;
+    t.tile_map = fwd_only ? h->ts_map0 : h->ts_map;
     const int cls = fwd_only ? GNN_K_FWD_GEMM0 : gsrc >= 2 ? GNN_K_UPDATE : GNN_K_GRAD_GEMM0;
     if (h->dtype == GNN_DTYPE_BF16) {
         if (staged) t.Ab[0] = h->xstage_b[h->xstage_cur];

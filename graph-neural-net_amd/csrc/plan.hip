@@ -88,6 +88,8 @@ void plan_chain(gnn_mlp *h) {
     auto give_up = [&](const char *what) {
         (void)hipGetLastError();
         if (h->slabs) { (void)hipFree(h->slabs); h->slabs = nullptr; }
+        if (h->ts_map) { (void)hipFree(h->ts_map); h->ts_map = nullptr; }
+        if (h->ts_map0) { (void)hipFree(h->ts_map0); h->ts_map0 = nullptr; }
         for (int i = 0; i < 2; i++) {
             if (h->xstage[i]) { (void)hipFree(h->xstage[i]); h->xstage[i] = nullptr; }
             if (h->xstage_b[i]) { (void)hipFree(h->xstage_b[i]); h->xstage_b[i] = nullptr; }
@@ -118,9 +120,24 @@ void plan_chain(gnn_mlp *h) {
         gl.tiling = make_xcd_tiling((gl.M + TS_TM - 1) / TS_TM, gl.N / TS_TN);
         gl.block_begin = tiles;
         tiles += gl.tiling.blocks();
-        if (l == 0) h->ts_tiles0 = tiles;
     }
-    h->ts_tiles = tiles;
+    {
+        // workgroup -> tile of the two grids (all layers; layer 0 alone for the chain's first launch)
+        TileMapLayer ml[MAX_LAYERS];
+        for (int l = 0; l < L - 1; l++) ml[l] = TileMapLayer{h->ld[l], h->ld[l + 1]};
+        hipDeviceProp_t prop{};
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount >= 8) cus = prop.multiProcessorCount;
+        else (void)hipGetLastError();
+        const std::vector<uint32_t> all = make_tile_map(ml, L - 1, cus / 8, true), first = make_tile_map(ml, 1, cus / 8, true);
+        auto upload = [&](const std::vector<uint32_t> &m, uint32_t **dst) {
+            if (hipMalloc(reinterpret_cast<void **>(dst), sizeof(uint32_t) * m.size()) != hipSuccess) { *dst = nullptr; return false; }
+            return hipMemcpy(*dst, m.data(), sizeof(uint32_t) * m.size(), hipMemcpyHostToDevice) == hipSuccess;
+        };
+        if (!upload(all, &h->ts_map) || !upload(first, &h->ts_map0)) { give_up("the workgroup -> tile maps could not be placed in device memory"); return; }
+        h->ts_tiles = (int)all.size();
+        h->ts_tiles0 = (int)first.size();
+    }
     t.slabs = h->slabs; t.slab_rows = h->cap_rows; t.ldz = h->ld[1];
     h->chain = true;
 }

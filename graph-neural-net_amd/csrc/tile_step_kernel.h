@@ -37,6 +37,10 @@
 #pragma once
 #include "fused_kernels.h"
 #include "gemm_bf16.h"
+#ifndef __HIPCC_RTC__
+#include <algorithm>
+#include <vector>
+#endif
 
 namespace gnn {
 
@@ -68,12 +72,83 @@ struct TileStepParams {
     // of THIS replica's bound gradient buffer (layer[l].G - Gself is the layer's offset in every peer's buffer); slice =
     // floats per owner (a multiple of 16), GSRC = 4 only
     const float *Gpeer[TS_MAX_PEERS]; int n_peer; const float *Gself; unsigned slice;
+    // workgroup -> tile: layer | tile row << 4 | tile column << 18, ~0 = idle (make_tile_map below)
+    const uint32_t *tile_map;
 };
+
+// Which workgroup takes which tile.  The dispatcher deals workgroup i to XCD i % 8 and, inside an XCD, the j-th of them to
+// the CU that also gets the (j + 32)-th (tools/tile_probe: HW_ID of every workgroup): with 284 live tiles for 256 CUs, 28 CUs
+// run two workgroups, and a pair of full layer-0 tiles took 5.2 us where a workgroup alone takes 4.0 -- the pair, not
+// the tile, set the kernel's duration.  The per-layer rectangles of XcdTiling also left two XCDs almost empty (a 13th tile
+// row of 16 weights) while the others ran 36-40 tiles on 32 CUs, idle blocks in the grid taking CU slots of live ones.
+// So the map is built on the host, tile by tile:
+//   * full layer-0 tiles ("heavy": gradient + update + the next batch's slab) go to the XCD of their rectangle
+//     (panels shared through that XCD's L2); every other tile (a partial last row, the small layers) to the XCD with the
+//     fewest tiles so far;
+//   * inside an XCD the lightest tiles take the slots that share a CU -- the first k and the last k when it has
+//     cus_per_xcd + k tiles -- and idle entries, if any, come last.
+// Placement changes which tile a workgroup computes and nothing else: results do not depend on it.
+struct TileMapLayer { int M, N; }; // padded rows / columns of W_l
+inline std::vector<uint32_t> make_tile_map(const TileMapLayer *layers, int n_layers, int cus_per_xcd, bool next_batch_slabs) {
+    struct T { uint32_t e; int w; };
+    std::vector<T> per_xcd[8];
+    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<T> light;
+    for (int l = 0; l < n_layers; l++) {
+        const int tiles_m = (layers[l].M + TS_TM - 1) / TS_TM, tiles_n = layers[l].N / TS_TN;
+        int full_m = 0; // tile rows that count as heavy: layer 0, more than half a tile of weights
+        if (l == 0) for (int tm = 0; tm < tiles_m; tm++) if (layers[l].M - tm * TS_TM > TS_TM / 2) full_m = tm + 1;
+        const XcdTiling rect = full_m > 0 ? make_xcd_tiling(full_m, tiles_n) : XcdTiling{};
+        for (int tm = 0; tm < tiles_m; tm++)
+            for (int tn = 0; tn < tiles_n; tn++) {
+                const int rows = layers[l].M - tm * TS_TM < TS_TM ? layers[l].M - tm * TS_TM : TS_TM;
+                // cost, measured (tools/tile_probe): a layer-0 tile takes ~4.0 us whatever its height (the next batch's slab is
+                // formed over all 128 rows either way), a tile of a later layer ~2.5 us
+                const T t{(uint32_t)l | (uint32_t)tm << 4 | (uint32_t)tn << 18, (l == 0 && next_batch_slabs) ? 100 + rows / 4 : rows};
+                if (l == 0 && tm < full_m) {
+                    const int x = (tm / rect.rm) * rect.xn + tn / rect.rn;
+                    per_xcd[x].push_back(t);
+                    load[x] += t.w;
+                } else light.push_back(t);
+            }
+    }
+    std::stable_sort(light.begin(), light.end(), [](const T &a, const T &b) { return a.w > b.w; });
+    for (const T &t : light) { // heaviest first, each to the XCD with the fewest tiles (ties: the least work, then the lowest id)
+        int best = 0;
+        for (int x = 1; x < 8; x++)
+            if (per_xcd[x].size() < per_xcd[best].size() || (per_xcd[x].size() == per_xcd[best].size() && load[x] < load[best])) best = x;
+        per_xcd[best].push_back(t);
+        load[best] += t.w;
+    }
+    size_t slots = 0;
+    for (int x = 0; x < 8; x++) slots = per_xcd[x].size() > slots ? per_xcd[x].size() : slots;
+    std::vector<uint32_t> map(slots * 8, ~0u);
+    for (int x = 0; x < 8; x++) {
+        std::vector<T> &v = per_xcd[x];
+        const int n = (int)v.size(), k = n > cus_per_xcd ? (n - cus_per_xcd < n / 2 ? n - cus_per_xcd : n / 2) : 0;
+        std::vector<int> order(n);
+        for (int i = 0; i < n; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return v[a].w < v[b].w; }); // lightest first
+        std::vector<char> is_light(n, 0);
+        std::vector<uint32_t> seq;
+        for (int i = k; i < 2 * k; i++) { seq.push_back(v[order[i]].e); is_light[order[i]] = 1; } // slots 0 .. k-1
+        for (int i = 0; i < k; i++) is_light[order[i]] = 1;
+        for (int i = 0; i < n; i++) if (!is_light[i]) seq.push_back(v[i].e);                       // the rest, in rectangle order
+        for (int i = 0; i < k; i++) seq.push_back(v[order[i]].e);                                  // the last k: the lightest of all
+        for (int j = 0; j < n; j++) map[(size_t)j * 8 + x] = seq[j];
+    }
+    return map;
+}
 
 // 16-B store that is written THROUGH the XCD's L2 (sc1): the line does not stay dirty, so the end of the kernel has nothing
 // to write back for it (a kernel boundary costs ~B / 6 TB/s for B dirty bytes, MI355X_MICROARCH.md, row `boundary`), and the
 // bytes leave while the kernel still runs.  Inline asm (the compiler has no spelling for it on a 16-B vector); the s_nop
 // covers the store-data hazard the compiler cannot see.  WT = false: a plain store.
+// (The value must come out of an ordinary vector instruction.  Stored straight from an MFMA's destination registers the
+//  asm statement read them before the matrix pipe had written them -- the wait states between an MFMA and a memory
+//  instruction that reads its result are the compiler's to insert, and it cannot see into inline asm: the bf16 kernel's
+//  slabs came out as garbage that changed from run to run.  ts_mfma_result() supplies them.)
+__device__ __forceinline__ void ts_mfma_result(f32x4 &v) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(v)); }
 template <bool WT> __device__ __forceinline__ void ts_store16(float *dst, f32x4 v) {
     if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
     else *reinterpret_cast<f32x4 *>(dst) = v;
@@ -132,16 +207,13 @@ __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fr = lane & 15, fq = lane >> 4;
 
-    int li = 0;
-#pragma unroll
-    for (int i = 1; i < MAX_LAYERS; i++)
-        if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].block_begin) li = i;
     // by value: one batch of scalar loads, not one round trip per field as it is first used; layer 0's descriptor (nine of
-    // ten workgroups) is requested at once, beside the block_begin fields that decide li, not behind them
+    // ten workgroups) is requested at once, beside the map entry that names the tile, not behind it
+    const uint32_t entry = p.tile_map[blockIdx.x];
     GradLayer L = p.layer[0];
+    if (entry == ~0u) return;
+    const int li = (int)(entry & 15u), tm = (int)((entry >> 4) & 0x3fffu), tn = (int)(entry >> 18);
     if (li != 0) L = p.layer[li];
-    int tm, tn;
-    if (!L.tiling.tile_of(blockIdx.x - L.block_begin, tm, tn)) return;
     const int m0 = tm * TS_TM, n0 = tn * TS_TN;
     const bool fwd = FWD && li == 0; // block-uniform
 
@@ -153,6 +225,10 @@ __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
 
     GNN_TS_STAMP(0);
     GNN_TS_STAMP_REAL(8);
+    if (STAMP && threadIdx.x == 0) { // where this workgroup runs: HW_ID (CU, SE, ..) and the XCC id
+        p.stamps[blockIdx.x * 16 + 10] = (unsigned)__builtin_amdgcn_s_getreg(0xF804);
+        p.stamps[blockIdx.x * 16 + 11] = (unsigned)__builtin_amdgcn_s_getreg(0xF814);
+    }
     // ---- everything this block reads first, all loads in flight together ------------------------
     // gradient operands of the first K chunk
     float4 va[4 * RPW], vd[RPW];
@@ -384,16 +460,13 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fr = lane & 15, fg = lane >> 4;
 
-    int li = 0;
-#pragma unroll
-    for (int i = 1; i < MAX_LAYERS; i++)
-        if (i < p.n_layers && (int)blockIdx.x >= p.layer[i].block_begin) li = i;
     // by value: one batch of scalar loads, not one round trip per field as it is first used; layer 0's descriptor (nine of
-    // ten workgroups) is requested at once, beside the block_begin fields that decide li, not behind them
+    // ten workgroups) is requested at once, beside the map entry that names the tile, not behind it
+    const uint32_t entry = p.tile_map[blockIdx.x];
     GradLayer L = p.layer[0];
+    if (entry == ~0u) return;
+    const int li = (int)(entry & 15u), tm = (int)((entry >> 4) & 0x3fffu), tn = (int)(entry >> 18);
     if (li != 0) L = p.layer[li];
-    int tm, tn;
-    if (!L.tiling.tile_of(blockIdx.x - L.block_begin, tm, tn)) return;
     const int m0 = tm * TS_TM, n0 = tn * TS_TN;
     const bool fwd = FWD && li == 0;
     const __bf16 *Ab = p.Ab[li], *Db = p.Db[li];
@@ -517,6 +590,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, join8(vn[0][0], vn[0][1]), z, 0, 0, 0);
             z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, join8(vn[1][0], vn[1][1]), z, 0, 0, 0);
+            ts_mfma_result(z);
             ts_store16<true>(slab + (size_t)(b0 + wave * 16 + fr) * p.ldz + n0 + 4 * fg, z); // rows n = 4fg + r, column b = fr
         }
     }

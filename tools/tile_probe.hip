@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <map>
 using namespace gnn;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -38,7 +39,28 @@ int main(int argc, char **argv) {
         gl.tiling = make_xcd_tiling((gl.M + TS_TM - 1) / TS_TM, gl.N / TS_TN); gl.block_begin = tiles; tiles += gl.tiling.blocks(); if (!l) tiles0 = tiles; }
     t.K = Bp; t.k_true = B; t.step_over_b = 1e-4f; t.momentum = 0.9f;
     t.An = An; t.ldan = ld[0]; t.next_rows = B; t.next_K = Bp; t.slabs = slabs; t.slab_rows = Bp; t.ldz = ld[1]; t.stamps = stamps;
-    printf("tiles: %d (layer 0: %d), %d slabs\n", tiles, tiles0, ns);
+    // workgroup -> tile: the per-layer XCD rectangles of rounds 2-3 (idle blocks included), and the host-built map
+    auto old_map = [&](int n_layers_used, int n_blocks) {
+        std::vector<uint32_t> m((size_t)n_blocks, ~0u);
+        for (int id = 0; id < n_blocks; id++) {
+            int li = 0;
+            for (int i = 1; i < n_layers_used; i++) if (id >= t.layer[i].block_begin) li = i;
+            const XcdTiling &x = t.layer[li].tiling;
+            const int loc = id - t.layer[li].block_begin, xx = loc & 7, j = loc >> 3, q = j / x.rn;
+            const int tm = (xx >> x.xs) * x.rm + q, tn = (xx & (x.xn - 1)) * x.rn + (j - q * x.rn);
+            if (tm < x.tiles_m && tn < x.tiles_n && q < x.rm) m[id] = (uint32_t)li | (uint32_t)tm << 4 | (uint32_t)tn << 18;
+        }
+        return m;
+    };
+    auto to_dev = [&](const std::vector<uint32_t> &m) { uint32_t *d; hipMalloc(&d, m.size() * 4); hipMemcpy(d, m.data(), m.size() * 4, hipMemcpyHostToDevice); return d; };
+    const int tiles_old = tiles, tiles0_old = tiles0;
+    const uint32_t *map_old = to_dev(old_map(3, tiles_old)), *map0_old = to_dev(old_map(1, tiles0_old));
+    TileMapLayer ml[3]; for (int l = 0; l < 3; l++) ml[l] = TileMapLayer{ld[l], ld[l + 1]};
+    const std::vector<uint32_t> hm = make_tile_map(ml, 3, 32, true), hm0 = make_tile_map(ml, 1, 32, true);
+    const uint32_t *map_new = to_dev(hm), *map0_new = to_dev(hm0);
+    tiles = (int)hm.size(); tiles0 = (int)hm0.size();
+    t.tile_map = map_new;
+    printf("tiles: %d (layer 0: %d) with the host-built map, %d (%d) with the rectangles of every layer; %d slabs\n", tiles, tiles0, tiles_old, tiles0_old, ns);
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto time_it = [&](const char *name, int n, auto fn) {
@@ -49,27 +71,37 @@ int main(int argc, char **argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-44s %8.2f us per call\n", name, ms * 1000.f / n);
     };
-    time_it("tile_step<grad, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 0>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+    {
+        TileStepParams o = t; o.tile_map = map_old;
+        time_it("tile_step<grad, update, fwd>, rectangles of every layer", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles_old), dim3(TS_THREADS), 0, s, o); });
+        time_it("tile_step<grad, update, fwd>, host-built map", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+        time_it("tile_step<grad, update, fwd>, rectangles of every layer", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles_old), dim3(TS_THREADS), 0, s, o); });
+        time_it("tile_step<grad, update, fwd>, host-built map", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+        TileStepParams o0 = t; o0.n_layers = 1; o0.tile_map = map0_old;
+        TileStepParams n0 = t; n0.n_layers = 1; n0.tile_map = map0_new;
+        time_it("tile_step<fwd only>, rectangles", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0_old), dim3(TS_THREADS), 0, s, o0); });
+        time_it("tile_step<fwd only>, host-built map", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, n0); });
+    }
     time_it("tile_step<grad, update, fwd> slabs write-through", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 1>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<grad, update, fwd> slabs + W, V write-through", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<grad, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 0>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<grad, update, fwd> slabs write-through", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 1>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<grad, update, fwd> slabs + W, V write-through", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     {   // a pair as in a real step: the tile kernel followed by a dependent small kernel (what the next launch waits for)
-        time_it("pair: tile_step + dependent fwd-only launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
-        time_it("pair: tile_step (write-through 2) + dependent launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
+        time_it("pair: tile_step + dependent fwd-only launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
+        time_it("pair: tile_step (write-through 2) + dependent launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
     }
     time_it("tile_step<grad, update, fwd> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
     time_it("tile_step<grad, update, fwd> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
     time_it("tile_step<grad, store G> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 1, false, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
-    time_it("tile_step<fwd only> 4 waves", 500, [&]() { TileStepParams u = t; u.n_layers = 1; hipLaunchKernelGGL((tile_step_kernel<0, 0, true, false, 4>), dim3(tiles0), dim3(256), 0, s, u); });
+    time_it("tile_step<fwd only> 4 waves", 500, [&]() { TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; hipLaunchKernelGGL((tile_step_kernel<0, 0, true, false, 4>), dim3(tiles0), dim3(256), 0, s, u); });
     time_it("tile_step<grad, update>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, false>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<grad, store G>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 1, false>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<G, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<2, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
-    time_it("tile_step<fwd only> (layer 0 tiles)", 500, [&]() { TileStepParams u = t; u.n_layers = 1; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
+    time_it("tile_step<fwd only> (layer 0 tiles)", 500, [&]() { TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
     {   // 4 waves against 8: the forward-only launch leaves W alone, so its slabs must agree bit for bit
         std::vector<float> s8((size_t)ns * Bp * ld[1]), s4(s8.size());
-        TileStepParams u = t; u.n_layers = 1;
+        TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new;
         hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u);
         CK(hipStreamSynchronize(s)); CK(hipMemcpy(s8.data(), slabs, s8.size() * 4, hipMemcpyDeviceToHost));
         CK(hipMemset(slabs, 0xff, s8.size() * 4));
@@ -91,6 +123,34 @@ int main(int argc, char **argv) {
         const unsigned long long *q = &hs[w * 16];
         printf("wg%-3d start+%.2f us: loads->LDS %llu | grad mfma %llu | reduce+update %llu | sW barrier %llu | fwd mfma %llu | store %llu | total %llu cycles (%.2f us)\n", w,
                (q[8] - t0) / 100.0, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] ? q[4] - q[3] : 0, q[5] ? q[5] - q[4] : 0, q[6] ? q[6] - q[5] : 0, (q[6] ? q[6] : q[3]) - q[0], (q[9] - q[8]) / 100.0);
+    }
+    // who shares a CU with whom: workgroups per (XCC, SE, CU), and the span of the members of shared CUs against the others
+    {
+        std::map<unsigned, std::vector<int>> cu;
+        for (int w = 0; w < tiles; w++) {
+            if (!hs[w * 16 + 8] || !hs[w * 16 + 9]) continue; // idle block (left before its first stamp)
+            const unsigned hw = (unsigned)hs[w * 16 + 10], xcc = (unsigned)hs[w * 16 + 11] & 15;
+            const unsigned key = (xcc << 16) | (((hw >> 13) & 7) << 8) | ((hw >> 8) & 15);
+            cu[key].push_back(w);
+        }
+        int n1 = 0, n2 = 0, n3 = 0; double d1 = 0, d2 = 0, e1 = 0, e2 = 0;
+        for (auto &kv : cu) {
+            const size_t n = kv.second.size();
+            (n == 1 ? n1 : n == 2 ? n2 : n3)++;
+            for (int w : kv.second) {
+                const double dur = (hs[w * 16 + 9] - hs[w * 16 + 8]) / 100.0, end = (hs[w * 16 + 9] - t0) / 100.0;
+                if (n == 1) { d1 = std::max(d1, dur); e1 = std::max(e1, end); } else { d2 = std::max(d2, dur); e2 = std::max(e2, end); }
+            }
+        }
+        printf("CUs with 1 / 2 / 3+ live workgroups: %d / %d / %d; longest workgroup alone on its CU %.2f us (ends +%.2f), sharing %.2f us (ends +%.2f)\n", n1, n2, n3, d1, e1, d2, e2);
+        int shown = 0;
+        for (auto &kv : cu) {
+            if (kv.second.size() < 2 || shown >= 12) continue;
+            printf("  xcc %u se %u cu %2u:", kv.first >> 16, (kv.first >> 8) & 255, kv.first & 255);
+            for (int w : kv.second) printf("  wg%-3d [+%.2f, +%.2f]", w, (hs[w * 16 + 8] - t0) / 100.0, (hs[w * 16 + 9] - t0) / 100.0);
+            printf("\n");
+            shown++;
+        }
     }
     return 0;
 }
