@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 #include <exception>
 #include <new>
 #include <string>
@@ -87,6 +88,7 @@ struct gnn_mlp {
     gnn::TileStepParams tsp{};
     int ts_tiles = 0, ts_tiles0 = 0; // blocks of all layers / of layer 0 alone
     uint32_t *ts_map = nullptr, *ts_map0 = nullptr; // workgroup -> tile of the two grids (make_tile_map), device memory
+    bool ts_map_args = false; uint32_t ts_map_words[2][gnn::TS_MAP_ARGS / 2]; // ... and packed for the kernel arguments ([0]: all layers, [1]: layer 0)
     float *slabs = nullptr;
     int n_slabs = 0;
     std::string plan_note;    // why the net is NOT on the two-launch path (empty when it is): gnn_mlp_plan_note

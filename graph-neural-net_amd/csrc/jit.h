@@ -123,16 +123,16 @@ inline const Specialised *get_middle4(int device, const int *dims, int L, int ac
 }
 
 // rowblock_kernel<RbStaticShape<dims...>, act, outk> (rowblock_kernel.h): the two-launch step's training kernel, fn[0].
-inline const Specialised *get_rowblock(int device, const int *dims, int L, int act, int outk, size_t lds_bytes) {
+inline const Specialised *get_rowblock(int device, const int *dims, int L, int act, int outk, bool bf16, size_t lds_bytes) {
     static std::mutex mu;
     static std::map<std::string, Specialised> cache;
-    const std::string key = std::to_string(device) + "|" + shape_list(dims, L) + "|" + std::to_string(act) + "|" + std::to_string(outk);
+    const std::string key = std::to_string(device) + "|" + shape_list(dims, L) + "|" + std::to_string(act) + "|" + std::to_string(outk) + (bf16 ? "|bf16" : "");
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second.fn[0] ? &it->second : nullptr;
     Specialised &sp = cache[key];
     sp.n_fn = 1;
-    const std::string expr = "gnn::rowblock_kernel<gnn::RbStaticShape<" + shape_list(dims, L) + ">, " + std::to_string(act) + ", " + std::to_string(outk) + ", false>";
+    const std::string expr = "gnn::rowblock_kernel<gnn::RbStaticShape<" + shape_list(dims, L) + ">, " + std::to_string(act) + ", " + std::to_string(outk) + ", false, 0, " + (bf16 ? "true" : "false") + ">";
     const std::string src = "#include \"rowblock_kernel.h\"\n";
     const char *hdr_src[] = {kEmbedded_kernels_h, kEmbedded_fused_kernels_h, kEmbedded_middle4_kernel_h, kEmbedded_rowblock_kernel_h};
     const char *hdr_name[] = {"kernels.h", "fused_kernels.h", "middle4_kernel.h", "rowblock_kernel.h"};

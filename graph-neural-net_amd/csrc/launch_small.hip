@@ -97,24 +97,26 @@ void plan_mid4(gnn_mlp *h) {
 // ---- rowblock_kernel plan -----------------------------------------------------------------------
 using RbMnistA = RbStaticShape<784, 300, 100, 10>;
 using RbMnistB = RbStaticShape<784, 100, 50, 10>;
-template <class SH> const void *rb_fn_static(int act) {
+template <class SH, bool BF> const void *rb_fn_static(int act) {
     switch (act) {
-    case 0: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 0, 0>);
-    case 1: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 1, 0>);
-    case 2: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 2, 0>);
-    case 3: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 3, 0>);
-    default: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 4, 0>);
+    case 0: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 0, 0, false, 0, BF>);
+    case 1: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 1, 0, false, 0, BF>);
+    case 2: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 2, 0, false, 0, BF>);
+    case 3: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 3, 0, false, 0, BF>);
+    default: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 4, 0, false, 0, BF>);
     }
 }
-template <int NL> const void *rb_fn_runtime(int out_kind) {
-    return out_kind == GNN_OUT_SOFTMAX_CE ? reinterpret_cast<const void *>(&rowblock_kernel<RbRuntimeShape<NL>, -1, 0>)
-                                          : reinterpret_cast<const void *>(&rowblock_kernel<RbRuntimeShape<NL>, -1, 1>);
+template <int NL, bool BF> const void *rb_fn_runtime(int out_kind) {
+    return out_kind == GNN_OUT_SOFTMAX_CE ? reinterpret_cast<const void *>(&rowblock_kernel<RbRuntimeShape<NL>, -1, 0, false, 0, BF>)
+                                          : reinterpret_cast<const void *>(&rowblock_kernel<RbRuntimeShape<NL>, -1, 1, false, 0, BF>);
 }
 
 void plan_rowblock(gnn_mlp *h) {
     h->rb = false;
     h->rb_fn = nullptr; h->rb_jit = nullptr; h->rb_static = 0;
-    if (!h->chain || h->dtype != GNN_DTYPE_F32 || h->env_rb_off) return;
+    const bool bf = h->dtype == GNN_DTYPE_BF16;
+    if (!h->chain || h->env_rb_off) return;
+    if (bf && h->L > 4) return; // (the bf16 form covers nets of three and four layers; deeper ones keep middle4_kernel<.., BF16>)
     RbParams &r = h->rbp;
     r = RbParams{};
     r.plan = make_rb_plan(h->dims.data(), h->L);
@@ -123,19 +125,24 @@ void plan_rowblock(gnn_mlp *h) {
     h->rb_lds_bytes = (size_t)r.plan.lds_floats * sizeof(float);
     for (int l = 1; l < Lm; l++) { r.W[l] = h->W + h->w_off[l]; r.act[l] = h->act[l]; }
     for (int l = 1; l <= Lm; l++) r.delta[l] = h->delta[l];
+    if (bf) {
+        for (int l = 1; l < Lm; l++) { r.Wb[l] = h->Wb + h->w_off[l]; r.actb[l] = h->actb[l]; }
+        for (int l = 1; l <= Lm; l++) r.deltab[l] = h->deltab[l];
+    }
     r.last_act = h->last_act;
     r.inner_act = h->inner_act;
     r.slabs = h->slabs; r.slab_rows = h->cap_rows;
     const bool allow_static = !h->env_static_off && h->out_kind == GNN_OUT_SOFTMAX_CE;
-    if (allow_static && shape_matches<ShapeMnistA>(h)) { h->rb_fn = rb_fn_static<RbMnistA>(h->inner_act); h->rb_static = 1; }
-    else if (allow_static && shape_matches<ShapeMnistB>(h)) { h->rb_fn = rb_fn_static<RbMnistB>(h->inner_act); h->rb_static = 1; }
+    if (allow_static && shape_matches<ShapeMnistA>(h)) { h->rb_fn = bf ? rb_fn_static<RbMnistA, true>(h->inner_act) : rb_fn_static<RbMnistA, false>(h->inner_act); h->rb_static = 1; }
+    else if (allow_static && shape_matches<ShapeMnistB>(h)) { h->rb_fn = bf ? rb_fn_static<RbMnistB, true>(h->inner_act) : rb_fn_static<RbMnistB, false>(h->inner_act); h->rb_static = 1; }
+    else if (bf) h->rb_fn = L == 3 ? rb_fn_runtime<3, true>(h->out_kind) : rb_fn_runtime<4, true>(h->out_kind);
     else {
         switch (L) {
-        case 3: h->rb_fn = rb_fn_runtime<3>(h->out_kind); break;
-        case 4: h->rb_fn = rb_fn_runtime<4>(h->out_kind); break;
-        case 5: h->rb_fn = rb_fn_runtime<5>(h->out_kind); break;
-        case 6: h->rb_fn = rb_fn_runtime<6>(h->out_kind); break;
-        default: h->rb_fn = rb_fn_runtime<0>(h->out_kind); break;
+        case 3: h->rb_fn = rb_fn_runtime<3, false>(h->out_kind); break;
+        case 4: h->rb_fn = rb_fn_runtime<4, false>(h->out_kind); break;
+        case 5: h->rb_fn = rb_fn_runtime<5, false>(h->out_kind); break;
+        case 6: h->rb_fn = rb_fn_runtime<6, false>(h->out_kind); break;
+        default: h->rb_fn = rb_fn_runtime<0, false>(h->out_kind); break;
         }
     }
     if (hipFuncSetAttribute(h->rb_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rb_lds_bytes) != hipSuccess) {
@@ -160,7 +167,7 @@ void try_specialize(gnn_mlp *h) {
     h->mid4_jit[2] = sp->fn[2];
     h->specialization = 2;
     if (h->rb && !h->rb_static) { // the training row-block kernel for this shape, from the same embedded sources
-        const jit::Specialised *rs = jit::get_rowblock(h->device, h->dims.data(), h->L, h->inner_act, h->out_kind, h->rb_lds_bytes);
+        const jit::Specialised *rs = jit::get_rowblock(h->device, h->dims.data(), h->L, h->inner_act, h->out_kind, h->dtype == GNN_DTYPE_BF16, h->rb_lds_bytes);
         if (rs) h->rb_jit = rs->fn[0];
     }
 }
@@ -257,6 +264,8 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
     const dim3 grid(fwd_only ? h->ts_tiles0 : h->ts_tiles), block(TS_THREADS);
     if (fwd_only) t.n_layers = 1;
     t.tile_map = fwd_only ? h->ts_map0 : h->ts_map;
+    t.map_in_args = h->ts_map_args ? 1 : 0;
+    if (h->ts_map_args) std::memcpy(t.map_words, h->ts_map_words[fwd_only ? 1 : 0], sizeof(t.map_words));
     const int cls = fwd_only ? GNN_K_FWD_GEMM0 : gsrc >= 2 ? GNN_K_UPDATE : GNN_K_GRAD_GEMM0;
     if (h->dtype == GNN_DTYPE_BF16) {
         if (staged) t.Ab[0] = h->xstage_b[h->xstage_cur];

@@ -24,9 +24,9 @@ void plan_fused(gnn_mlp *h) {
     if (h->dtype != GNN_DTYPE_F32) {
         // bf16 operands: per-layer GEMMs (gemm_bf16.h) for inference and for nets off the row-block path; training
         // of a net that fits the row-block kernel takes the two-launch path in bf16 (tile_step_bf16_kernel + the bf16
-        // instance of middle4_kernel)
+        // instance of rowblock_kernel, or of middle4_kernel where that one does not apply)
         plan_mid4(h);
-        if (h->mid4) plan_chain(h);
+        if (h->mid4) { plan_chain(h); plan_rowblock(h); }
         if (!h->chain) h->mid4 = false;
         if (!h->chain && h->plan_note.empty()) h->plan_note = "bf16: the row-block kernel exists for the two-launch path only; per-layer bf16 GEMMs";
         return;
@@ -137,6 +137,7 @@ void plan_chain(gnn_mlp *h) {
         if (!upload(all, &h->ts_map) || !upload(first, &h->ts_map0)) { give_up("the workgroup -> tile maps could not be placed in device memory"); return; }
         h->ts_tiles = (int)all.size();
         h->ts_tiles0 = (int)first.size();
+        h->ts_map_args = pack_tile_map(all, h->ts_map_words[0]) && pack_tile_map(first, h->ts_map_words[1]);
     }
     t.slabs = h->slabs; t.slab_rows = h->cap_rows; t.ldz = h->ld[1];
     h->chain = true;

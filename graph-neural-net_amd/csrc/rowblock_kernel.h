@@ -40,6 +40,7 @@ struct RbPlan {
     int off_act[MAX_LAYERS]; // activation images l = 1..L-2: [4][ld[l]+4]
     int off_dl[MAX_LAYERS];  // delta images l = 2..L-1: [4][ld[l]+4]
     int off_y, off_scratch;
+    int off_fp1;             // bf16 kernels: f'(a_1) from the unrounded activation, [4][ld[1]+4] (middle4_kernel.h keeps the same image)
     // forward register products giving layer l+1 from image-less W_l, l = 1..L-3 (the last product is the row tail's)
     int cs[MAX_LAYERS];      // column slices of 128 (waves = ksf * cs = 8)
     int ksf[MAX_LAYERS];     // K slices = partial tiles per output element
@@ -82,6 +83,7 @@ __host__ __device__ constexpr RbPlan make_rb_plan(const int *dims, int L) {
     for (int l = 1; l < Lm; l++) { m.off_act[l] = off; off += 4 * (m.ld[l] + 4); }
     for (int l = 2; l <= Lm; l++) { m.off_dl[l] = off; off += 4 * (m.ld[l] + 4); }
     m.off_y = off; off += 4 * m.ld[Lm];
+    m.off_fp1 = off; off += 4 * (m.ld[1] + 4);
     m.off_scratch = off;
     int scratch = 0;
     for (int l = 1; l + 1 < Lm; l++) { // forward products from registers
@@ -118,7 +120,24 @@ struct RbParams {
     const int32_t *row_idx;      // optional: expected row of batch row r is Y row row_idx[r] (sampled batches)
     const float *slabs; int slab_rows; // slab s of batch row b at slabs[(s * slab_rows + b) * ld[1]] (tile_step_kernel.h)
     unsigned long long *stamps;  // STAMP builds only: 16 slots per workgroup
+    // bf16 kernels (BF): the bf16 shadow of W_l and the bf16 outputs the tile kernel reads, as in Mid4Params
+    const __bf16 *Wb[MAX_LAYERS];
+    __bf16 *actb[MAX_LAYERS];
+    __bf16 *deltab[MAX_LAYERS];
 };
+
+// four bf16 weights (8 B of the shadow) widened to the f32 values they stand for
+__device__ __forceinline__ f32x4 rb_widen4(uint2 u) {
+    f32x4 w;
+    w[0] = __builtin_bit_cast(float, u.x << 16); w[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    w[2] = __builtin_bit_cast(float, u.y << 16); w[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    return w;
+}
+// the weights a thread's float4 slot holds: 16 B of the f32 masters, or (BF) 8 B of the bf16 shadow at the same element offset
+template <bool BF> __device__ __forceinline__ f32x4 rb_load_w4(const float *W, const __bf16 *Wb, unsigned off) {
+    if constexpr (BF) return rb_widen4(*reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(Wb) + (size_t)(off * 2u)));
+    else return m4_load16(W, off);
+}
 
 template <int... DIMS> struct RbStaticShape {
     static constexpr bool is_static = true;
@@ -214,7 +233,7 @@ __device__ __forceinline__ void rowblock_backward_pair(const float *A_img, int l
 }
 
 // NL > 0: layer count fixed at compile time; IS_STATIC: `m` is a compile-time constant (every extent folds)
-template <int NL, bool IS_STATIC, int ACT_T, int OUTK, bool STAMP, int NSV, int UPW1, int TUNE>
+template <int NL, bool IS_STATIC, int ACT_T, int OUTK, bool STAMP, int NSV, int UPW1, int TUNE, bool BF>
 __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     const int ACT = (ACT_T >= 0) ? ACT_T : p.inner_act;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -222,6 +241,11 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int row0 = blockIdx.x * 4;
     const int L = (NL > 0) ? NL : m.L, Lm = L - 1;
+    // BF (GNN_DTYPE_BF16, nets of three and four layers): every operand of the products carries a bf16 value -- weights from
+    // the bf16 shadow (half the bytes of the kernel's dominant load), activations and deltas rounded as they enter their
+    // operand images, f' kept from the UNROUNDED activation -- on the same exact-f32 MFMA, outputs for the tile kernel in
+    // bf16: middle4_kernel<.., BF16>'s arithmetic in this kernel's schedule.
+    auto opv = [](float x) { return BF ? bf16_value(x) : x; };
     GNN_RB_STAMP(0);
 
     // ---- phase 0 / 1: loads, and A_1 = f(sum of the slabs, slab order) ------------------------------------------------
@@ -247,7 +271,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     // the last weight image (the row tail reads it from LDS): one small load
     const int c4l = m.kr[Lm] >> 2, nl4 = m.kr[Lm - 1] * c4l; // float4s of the last image's logical columns (<= 128 * 4)
     const int wl_r = IS_STATIC ? t / c4l : (int)(((unsigned)t * (((1u << 22) + c4l - 1) / c4l)) >> 22), wl_c = t - wl_r * c4l;
-    const f32x4 wl = m4_load16(p.W[Lm - 1], t < nl4 ? (unsigned)(wl_r * m.ld[Lm] + 4 * wl_c) : 0u);
+    const f32x4 wl = rb_load_w4<BF>(p.W[Lm - 1], p.Wb[Lm - 1], t < nl4 ? (unsigned)(wl_r * m.ld[Lm] + 4 * wl_c) : 0u);
     __builtin_amdgcn_sched_barrier(0);
     // this wave's K slice of the first register product (W_1 -> layer 2): 8-row units, 16 B per lane
     //     lane (hq, lq): rows 8u + 4hq + 0..3 of the unit, columns 128 cslice + 4 lq .. +3
@@ -264,7 +288,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 #pragma unroll
         for (int tt = 0; tt < 4; tt++) {
             const int k = 8 * u + 4 * hq + tt;
-            w1[UPW1 > 0 ? uu : 0][tt] = m4_load16(p.W[1], (unsigned)(k * m.ld[2] + colc_1));
+            w1[UPW1 > 0 ? uu : 0][tt] = rb_load_w4<BF>(p.W[1], p.Wb[1], (unsigned)(k * m.ld[2] + colc_1));
         }
     };
     // The copy of a wave's weight rows to the LDS image (for the backward product) costs the LDS store path 13 cycles per
@@ -325,6 +349,12 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         f32x4 a;
 #pragma unroll
         for (int j = 0; j < 4; j++) a[j] = (lrow && a1_q * 4 + j < m.d[1]) ? act_fn(ACT, z[j]) : 0.f;
+        if (BF) { // f' from the unrounded activation, then the operand value
+            f32x4 fp;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { fp[j] = act_prime_from_a(ACT, a[j]); a[j] = bf16_value(a[j]); }
+            if (a1_on) *reinterpret_cast<f32x4 *>(smem + m.off_fp1 + a1_r * (m.ld[1] + 4) + a1_q * 4) = fp;
+        }
         if (a1_on) {
             *reinterpret_cast<f32x4 *>(smem + m.off_act[1] + a1_r * (m.ld[1] + 4) + a1_q * 4) = a;
             a1v = a;
@@ -355,7 +385,10 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     // A_1 for the tile kernel: stored LAST.  The memory counter counts stores too, and the copies above wait for "all but
     // the youngest request" (what a wave without slabs needs): with the store in front of them the slab waves sat out its
     // round trip to L2 in front of the barrier.
-    if (a1_goff != 0xffffffffu) *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(p.act[1]) + (size_t)(a1_goff * 4u)) = a1v;
+    if (a1_goff != 0xffffffffu) {
+        if (BF) *reinterpret_cast<m4_bf16x4 *>(reinterpret_cast<char *>(p.actb[1]) + (size_t)(a1_goff * 2u)) = (m4_bf16x4){(__bf16)a1v[0], (__bf16)a1v[1], (__bf16)a1v[2], (__bf16)a1v[3]};
+        else *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(p.act[1]) + (size_t)(a1_goff * 4u)) = a1v;
+    }
     GNN_RB_WSTAMP(0); // this wave at the A_1 barrier
     __syncthreads();
     GNN_RB_STAMP(1);
@@ -487,7 +520,15 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                     for (int ks = 0; ks < KS; ks++) v += *reinterpret_cast<const f32x4 *>(smem + m.off_scratch + (ks * 4 + r) * N + n);
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = (row < p.B && n + j < m.d[l + 1]) ? act_fn(ACT, v[j]) : 0.f;
-                *reinterpret_cast<f32x4 *>(p.act[l + 1] + (size_t)row * N + n) = v;
+                if (BF) { // f'(a_l) parks in delta_l's image until delta_l itself is formed below
+                    f32x4 fp;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { fp[j] = act_prime_from_a(ACT, v[j]); v[j] = bf16_value(v[j]); }
+                    *reinterpret_cast<f32x4 *>(smem + m.off_dl[l + 1] + r * (N + 4) + n) = fp;
+                    *reinterpret_cast<m4_bf16x4 *>(p.actb[l + 1] + (size_t)row * N + n) = (m4_bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                } else {
+                    *reinterpret_cast<f32x4 *>(p.act[l + 1] + (size_t)row * N + n) = v;
+                }
                 *reinterpret_cast<f32x4 *>(smem + m.off_act[l + 1] + r * (N + 4) + n) = v; // (read back below by this very wave)
                 if (STAMP) asm volatile("" : "+v"(v));
             }
@@ -601,8 +642,14 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         float *dlast = smem + m.off_dl[Lm] + r * (16 + 4);
         if (kg == 0) {
             if (p.prob) *reinterpret_cast<f32x4 *>(p.prob + (size_t)row * 16 + 4 * q) = out4;
+            if (BF) {
+                *reinterpret_cast<m4_bf16x4 *>(p.deltab[Lm] + (size_t)row * 16 + 4 * q) = (m4_bf16x4){(__bf16)dd4[0], (__bf16)dd4[1], (__bf16)dd4[2], (__bf16)dd4[3]};
+#pragma unroll
+                for (int j = 0; j < 4; j++) dd4[j] = bf16_value(dd4[j]);
+            } else {
+                *reinterpret_cast<f32x4 *>(p.delta[Lm] + (size_t)row * 16 + 4 * q) = dd4;
+            }
             *reinterpret_cast<f32x4 *>(dlast + 4 * q) = dd4;
-            *reinterpret_cast<f32x4 *>(p.delta[Lm] + (size_t)row * 16 + 4 * q) = dd4;
         }
         if (lane == 0) {
             if (p.loss) p.loss[row] = row < p.B ? lsum : 0.f;
@@ -636,9 +683,13 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 #pragma unroll
                                 for (int j = 0; j < 4; j++) accd = __builtin_fmaf(d4[qq][j], wn[half][qq][j], accd);
                     }
-                    const float v = (row < p.B && n < m.d[Lm - 1]) ? accd * act_prime_from_a(ACT, an[half]) : 0.f;
-                    if (Lm - 1 > 1) smem[m.off_dl[Lm - 1] + r * (ldp + 4) + n] = v;
-                    p.delta[Lm - 1][(size_t)row * ldp + n] = v;
+                    // (BF: f' of the unrounded activation was parked by the forward pass -- in delta_{L-2}'s own slot, or in the
+                    //  f'(a_1) image when layer L-2 is layer 1)
+                    const float fpv = BF ? smem[((Lm - 1 > 1) ? m.off_dl[Lm - 1] : m.off_fp1) + r * (ldp + 4) + n] : act_prime_from_a(ACT, an[half]);
+                    const float v = (row < p.B && n < m.d[Lm - 1]) ? accd * fpv : 0.f;
+                    if (Lm - 1 > 1) smem[m.off_dl[Lm - 1] + r * (ldp + 4) + n] = opv(v);
+                    if (BF) p.deltab[Lm - 1][(size_t)row * ldp + n] = (__bf16)v;
+                    else p.delta[Lm - 1][(size_t)row * ldp + n] = v;
                 }
             }
         }
@@ -692,10 +743,12 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
             if (n < N) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float al = smem[m.off_act[l] + r * (N + 4) + n]; // f'(z_l) from a_l = f(z_l)
-                    const float v = (row0 + r < p.B && n < m.d[l]) ? acc[r] * act_prime_from_a(ACT, al) : 0.f;
-                    p.delta[l][(size_t)(row0 + r) * N + n] = v;
-                    if (l > 1) smem[m.off_dl[l] + r * (N + 4) + n] = v;
+                    // f'(z_l) from a_l = f(z_l); BF: parked by the forward pass (from the unrounded a_l) in delta_l's slot / the f'(a_1) image
+                    const float al = smem[(BF ? (l > 1 ? m.off_dl[l] : m.off_fp1) : m.off_act[l]) + r * (N + 4) + n];
+                    const float v = (row0 + r < p.B && n < m.d[l]) ? acc[r] * (BF ? al : act_prime_from_a(ACT, al)) : 0.f;
+                    if (BF) p.deltab[l][(size_t)(row0 + r) * N + n] = (__bf16)v;
+                    else p.delta[l][(size_t)(row0 + r) * N + n] = v;
+                    if (l > 1) smem[m.off_dl[l] + r * (N + 4) + n] = opv(v);
                 }
             }
         }
@@ -707,14 +760,15 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 }
 
 // TUNE: development knob of tools/rowblock_probe (0 = the shipped schedule)
-template <class SH, int ACT, int OUTK, bool STAMP = false, int TUNE = 0>
+template <class SH, int ACT, int OUTK, bool STAMP = false, int TUNE = 0, bool BF = false>
 __global__ __launch_bounds__(RB_NT) void rowblock_kernel(RbParams p) {
+    static_assert(!BF || SH::kL == 3 || SH::kL == 4, "the bf16 row-block kernel: nets of three and four layers");
     if constexpr (SH::is_static) {
         constexpr RbPlan m = SH::make(); // a LOCAL constexpr object: member accesses with constant indices fold to immediates
         static_assert(m.ok, "this shape does not fit the row-block kernel");
-        rowblock_body<SH::kL, true, ACT, OUTK, STAMP, m.ns, (SH::kL >= 4 ? m.upw[1] : 0), TUNE>(m, p);
+        rowblock_body<SH::kL, true, ACT, OUTK, STAMP, m.ns, (SH::kL >= 4 ? m.upw[1] : 0), TUNE, BF>(m, p);
     } else {
-        rowblock_body<SH::kL, false, ACT, OUTK, STAMP, MID4_MAX_SLABS, (SH::kL == 3 ? 0 : RB_MAXU), TUNE>(p.plan, p);
+        rowblock_body<SH::kL, false, ACT, OUTK, STAMP, MID4_MAX_SLABS, (SH::kL == 3 ? 0 : RB_MAXU), TUNE, BF>(p.plan, p);
     }
 }
 

@@ -47,6 +47,7 @@ namespace gnn {
 constexpr int TS_TM = 64, TS_TN = 16, TS_THREADS = 512, TS_KC = 128;
 constexpr int TS_MAX_SLABS = 16; // middle4_kernel keeps one float4 per slab in registers
 constexpr int TS_MAX_PEERS = 16; // replicas of one data-parallel handle (dp_handle.h: DP_MAX_REPLICAS)
+constexpr int TS_MAP_ARGS = 640; // workgroup -> tile entries that travel in the kernel arguments
 
 struct TileStepParams {
     GradLayer layer[MAX_LAYERS]; // tiling in 64 x 16 tiles; block_begin per layer
@@ -74,6 +75,11 @@ struct TileStepParams {
     const float *Gpeer[TS_MAX_PEERS]; int n_peer; const float *Gself; unsigned slice;
     // workgroup -> tile: layer | tile row << 4 | tile column << 18, ~0 = idle (make_tile_map below)
     const uint32_t *tile_map;
+    // the same map inside the kernel arguments, 16 bits per workgroup (layer | row << 3 | column << 9, 0xffff = idle), when
+    // the grid has at most TS_MAP_ARGS entries: the entry then arrives with the first batch of scalar loads instead of
+    // one more round trip to memory in front of everything a workgroup does (~700 cycles in tools/tile_probe's stamps)
+    int map_in_args;
+    uint32_t map_words[TS_MAP_ARGS / 2];
 };
 
 // Which workgroup takes which tile.  The dispatcher deals workgroup i to XCD i % 8 and, inside an XCD, the j-th of them to
@@ -138,6 +144,21 @@ inline std::vector<uint32_t> make_tile_map(const TileMapLayer *layers, int n_lay
         for (int j = 0; j < n; j++) map[(size_t)j * 8 + x] = seq[j];
     }
     return map;
+}
+// the 16-bit form for the kernel arguments; false when the grid or a field does not fit
+inline bool pack_tile_map(const std::vector<uint32_t> &map, uint32_t (&words)[TS_MAP_ARGS / 2]) {
+    if (map.size() > (size_t)TS_MAP_ARGS) return false;
+    for (uint32_t &w : words) w = 0xffffffffu;
+    for (size_t i = 0; i < map.size(); i++) {
+        uint32_t e16 = 0xffffu;
+        if (map[i] != ~0u) {
+            const uint32_t li = map[i] & 15u, tm = (map[i] >> 4) & 0x3fffu, tn = map[i] >> 18;
+            if (li > 7 || tm > 63 || tn > 126) return false;
+            e16 = li | tm << 3 | tn << 9;
+        }
+        words[i >> 1] = (i & 1) ? ((words[i >> 1] & 0x0000ffffu) | e16 << 16) : ((words[i >> 1] & 0xffff0000u) | e16);
+    }
+    return true;
 }
 
 // 16-B store that is written THROUGH the XCD's L2 (sc1): the line does not stay dirty, so the end of the kernel has nothing
@@ -209,10 +230,17 @@ __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
 
     // by value: one batch of scalar loads, not one round trip per field as it is first used; layer 0's descriptor (nine of
     // ten workgroups) is requested at once, beside the map entry that names the tile, not behind it
-    const uint32_t entry = p.tile_map[blockIdx.x];
+    int li, tm, tn;
     GradLayer L = p.layer[0];
-    if (entry == ~0u) return;
-    const int li = (int)(entry & 15u), tm = (int)((entry >> 4) & 0x3fffu), tn = (int)(entry >> 18);
+    if (p.map_in_args) {
+        const uint32_t w = p.map_words[blockIdx.x >> 1], e = (blockIdx.x & 1) ? w >> 16 : w & 0xffffu;
+        if (e == 0xffffu) return;
+        li = (int)(e & 7u); tm = (int)((e >> 3) & 63u); tn = (int)(e >> 9);
+    } else {
+        const uint32_t e = p.tile_map[blockIdx.x];
+        if (e == ~0u) return;
+        li = (int)(e & 15u); tm = (int)((e >> 4) & 0x3fffu); tn = (int)(e >> 18);
+    }
     if (li != 0) L = p.layer[li];
     const int m0 = tm * TS_TM, n0 = tn * TS_TN;
     const bool fwd = FWD && li == 0; // block-uniform
@@ -462,10 +490,17 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
 
     // by value: one batch of scalar loads, not one round trip per field as it is first used; layer 0's descriptor (nine of
     // ten workgroups) is requested at once, beside the map entry that names the tile, not behind it
-    const uint32_t entry = p.tile_map[blockIdx.x];
+    int li, tm, tn;
     GradLayer L = p.layer[0];
-    if (entry == ~0u) return;
-    const int li = (int)(entry & 15u), tm = (int)((entry >> 4) & 0x3fffu), tn = (int)(entry >> 18);
+    if (p.map_in_args) {
+        const uint32_t w = p.map_words[blockIdx.x >> 1], e = (blockIdx.x & 1) ? w >> 16 : w & 0xffffu;
+        if (e == 0xffffu) return;
+        li = (int)(e & 7u); tm = (int)((e >> 3) & 63u); tn = (int)(e >> 9);
+    } else {
+        const uint32_t e = p.tile_map[blockIdx.x];
+        if (e == ~0u) return;
+        li = (int)(e & 15u); tm = (int)((e >> 4) & 0x3fffu); tn = (int)(e >> 18);
+    }
     if (li != 0) L = p.layer[li];
     const int m0 = tm * TS_TM, n0 = tn * TS_TN;
     const bool fwd = FWD && li == 0;

@@ -60,6 +60,7 @@ int main(int argc, char **argv) {
     const uint32_t *map_new = to_dev(hm), *map0_new = to_dev(hm0);
     tiles = (int)hm.size(); tiles0 = (int)hm0.size();
     t.tile_map = map_new;
+    t.map_in_args = pack_tile_map(hm, t.map_words) ? 1 : 0;
     printf("tiles: %d (layer 0: %d) with the host-built map, %d (%d) with the rectangles of every layer; %d slabs\n", tiles, tiles0, tiles_old, tiles0_old, ns);
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -72,13 +73,16 @@ int main(int argc, char **argv) {
         printf("%-44s %8.2f us per call\n", name, ms * 1000.f / n);
     };
     {
-        TileStepParams o = t; o.tile_map = map_old;
+        TileStepParams o = t; o.tile_map = map_old; o.map_in_args = 0;
+        TileStepParams tg = t; tg.map_in_args = 0; // the host-built map read from memory
         time_it("tile_step<grad, update, fwd>, rectangles of every layer", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles_old), dim3(TS_THREADS), 0, s, o); });
-        time_it("tile_step<grad, update, fwd>, host-built map", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+        time_it("tile_step<grad, update, fwd>, host-built map in the kernel arguments", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+        time_it("tile_step<grad, update, fwd>, host-built map read from memory", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, tg); });
         time_it("tile_step<grad, update, fwd>, rectangles of every layer", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles_old), dim3(TS_THREADS), 0, s, o); });
-        time_it("tile_step<grad, update, fwd>, host-built map", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
-        TileStepParams o0 = t; o0.n_layers = 1; o0.tile_map = map0_old;
-        TileStepParams n0 = t; n0.n_layers = 1; n0.tile_map = map0_new;
+        time_it("tile_step<grad, update, fwd>, host-built map in the kernel arguments", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
+        time_it("tile_step<grad, update, fwd>, host-built map read from memory", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, tg); });
+        TileStepParams o0 = t; o0.n_layers = 1; o0.tile_map = map0_old; o0.map_in_args = 0;
+        TileStepParams n0 = t; n0.n_layers = 1; n0.tile_map = map0_new; n0.map_in_args = pack_tile_map(hm0, n0.map_words) ? 1 : 0;
         time_it("tile_step<fwd only>, rectangles", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0_old), dim3(TS_THREADS), 0, s, o0); });
         time_it("tile_step<fwd only>, host-built map", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, n0); });
     }
@@ -88,20 +92,20 @@ int main(int argc, char **argv) {
     time_it("tile_step<grad, update, fwd> slabs write-through", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 1>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<grad, update, fwd> slabs + W, V write-through", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     {   // a pair as in a real step: the tile kernel followed by a dependent small kernel (what the next launch waits for)
-        time_it("pair: tile_step + dependent fwd-only launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
-        time_it("pair: tile_step (write-through 2) + dependent launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
+        time_it("pair: tile_step + dependent fwd-only launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; u.map_in_args = pack_tile_map(hm0, u.map_words) ? 1 : 0; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
+        time_it("pair: tile_step (write-through 2) + dependent launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; u.map_in_args = pack_tile_map(hm0, u.map_words) ? 1 : 0; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
     }
     time_it("tile_step<grad, update, fwd> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
     time_it("tile_step<grad, update, fwd> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
     time_it("tile_step<grad, store G> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 1, false, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
-    time_it("tile_step<fwd only> 4 waves", 500, [&]() { TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; hipLaunchKernelGGL((tile_step_kernel<0, 0, true, false, 4>), dim3(tiles0), dim3(256), 0, s, u); });
+    time_it("tile_step<fwd only> 4 waves", 500, [&]() { TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; u.map_in_args = pack_tile_map(hm0, u.map_words) ? 1 : 0; hipLaunchKernelGGL((tile_step_kernel<0, 0, true, false, 4>), dim3(tiles0), dim3(256), 0, s, u); });
     time_it("tile_step<grad, update>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, false>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<grad, store G>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 1, false>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
     time_it("tile_step<G, update, fwd>", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<2, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); });
-    time_it("tile_step<fwd only> (layer 0 tiles)", 500, [&]() { TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
+    time_it("tile_step<fwd only> (layer 0 tiles)", 500, [&]() { TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; u.map_in_args = pack_tile_map(hm0, u.map_words) ? 1 : 0; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
     {   // 4 waves against 8: the forward-only launch leaves W alone, so its slabs must agree bit for bit
         std::vector<float> s8((size_t)ns * Bp * ld[1]), s4(s8.size());
-        TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new;
+        TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; u.map_in_args = pack_tile_map(hm0, u.map_words) ? 1 : 0;
         hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u);
         CK(hipStreamSynchronize(s)); CK(hipMemcpy(s8.data(), slabs, s8.size() * 4, hipMemcpyDeviceToHost));
         CK(hipMemset(slabs, 0xff, s8.size() * 4));
