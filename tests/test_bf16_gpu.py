@@ -102,3 +102,39 @@ def test_bf16_full_size_properties(gnn):
         n = dims[l] * dims[l + 1]
         ref_l = gq[off:off + n].reshape(dims[l], dims[l + 1]); off += n
         assert np.abs(full[l] - ref_l).max() <= 4e-3 * np.abs(ref_l).max() + 1e-7, "layer %d" % l
+
+
+@pytest.mark.parametrize("dims,B,inner", [([784, 300, 100, 10], 128, LEAKY), ([784, 100, 50, 10], 32, LEAKY),
+                                          ([300, 40, 10], 17, SIGMOID), ([20, 17, 33, 7], 19, LEAKY)])
+def test_bf16_rowblock_kernel_against_middle4(gnn, monkeypatch, dims, B, inner):
+    """The bf16 form of the two-launch step's row-block kernel (csrc/rowblock_kernel.h, BF: nets of three and four
+    layers) against middle4_kernel<.., BF16> (GNN_MLP_ROWBLOCK=0): the same roundings at the same places, another
+    summation order of the middle products -- so a bf16 value here and there lands on its neighbour and the two runs
+    drift apart by bf16 steps, not more -- and both within the bf16-aware oracle's tolerance after three steps."""
+    import os
+    if os.environ.get("GNN_MLP_PATH") or os.environ.get("GNN_MLP_CHAIN") == "0" or os.environ.get("GNN_MLP_ROWBLOCK") == "0":
+        pytest.skip("path forced by the environment")
+    nb, n = 3, 3
+    X, Y = batch(dims, B * nb, 57)
+    new = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, dtype=gnn.DTYPE_BF16, max_batch=B)
+    monkeypatch.setenv("GNN_MLP_ROWBLOCK", "0")
+    old = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, dtype=gnn.DTYPE_BF16, max_batch=B)
+    monkeypatch.delenv("GNN_MLP_ROWBLOCK")
+    assert new.step_launches == 2 and old.step_launches == 2
+    assert new.rowblock_state in (1, 2) and old.rowblock_state == 0
+    w0 = new.get_weights()
+    assert np.array_equal(w0, old.get_weights())
+    # one gradient, element by element, before anything moved
+    gn, go = new.calculateWeightGradient(X[:B], Y[:B]), old.calculateWeightGradient(X[:B], Y[:B])
+    for l in range(len(dims) - 1):
+        assert np.abs(gn[l] - go[l]).max() <= 4e-3 * np.abs(go[l]).max() + 1e-7, "layer %d" % l
+    new.upload_dataset(X, Y); old.upload_dataset(X, Y)
+    new.train_range(0, B, n, 0.0125, 0.9)
+    old.train_range(0, B, n, 0.0125, 0.9)
+    assert np.abs(new.get_weights() - old.get_weights()).max() <= 3e-4
+    w, v = w0.copy(), np.zeros_like(w0)
+    X32 = X.astype(np.float32).astype(np.float64)
+    for s in range(n):
+        sl = slice((s % nb) * B, (s % nb + 1) * B)
+        w, v = np_oracle.gradient_step_bf16(w, v, dims, X32[sl], Y[sl], 0.0125, 0.9, inner)
+    assert np.abs(new.get_weights() - w).max() <= 3e-4
