@@ -386,6 +386,31 @@ __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
                 const float *ap = &sA[fq * LDA + wave * 16 + fr];
                 const float *dp = &sD[fq * LDD + fr];
                 int kk = 0;
+                if (kc == TS_KC) {
+                    // a whole chunk (every step at B = 128): the operands of trip t + 1 are requested before the MFMAs of trip t --
+                    // trip by trip, the first MFMA of every trip waited out an LDS round trip that nothing covered (one wave per
+                    // SIMD here).  The same MFMAs on the same accumulators in the same order as the loop below.  (All 64 reads up
+                    // front took 148 registers: two workgroups no longer fit a CU, and 28 CUs hold two.)
+                    float a[2][8], d[2][8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { a[0][j] = ap[(4 * j) * LDA]; d[0][j] = dp[(4 * j) * LDD]; }
+#pragma unroll
+                    for (int trip = 0; trip < TS_KC / 32; trip++) {
+                        const int cur = trip & 1;
+                        if (trip + 1 < TS_KC / 32) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) { a[cur ^ 1][j] = ap[(32 * (trip + 1) + 4 * j) * LDA]; d[cur ^ 1][j] = dp[(32 * (trip + 1) + 4 * j) * LDD]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 8; j += 2) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(d[cur][j], a[cur][j], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(d[cur][j + 1], a[cur][j + 1], acc1, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    kk = TS_KC;
+                }
                 for (; kk + 32 <= kc; kk += 32) { // 8 MFMAs per trip, the trip's 16 LDS reads issued first
                     float a[8], d[8];
 #pragma unroll
