@@ -288,7 +288,8 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 #pragma unroll
         for (int tt = 0; tt < 4; tt++) {
             const int k = 8 * u + 4 * hq + tt;
-            w1[UPW1 > 0 ? uu : 0][tt] = rb_load_w4<BF>(p.W[1], p.Wb[1], (unsigned)(k * m.ld[2] + colc_1));
+            if (TUNE & (1 << 20)) w1[UPW1 > 0 ? uu : 0][tt] = (f32x4){0.01f * (float)k, 0.f, 0.02f, 0.f}; // (probe: what the weight stream costs -- no loads, wrong results)
+            else w1[UPW1 > 0 ? uu : 0][tt] = rb_load_w4<BF>(p.W[1], p.Wb[1], (unsigned)(k * m.ld[2] + colc_1));
         }
     };
     // The copy of a wave's weight rows to the LDS image (for the backward product) costs the LDS store path 13 cycles per
@@ -337,7 +338,8 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 #pragma unroll
         for (int i = 0; i < NSV; i++) {
             const unsigned o = zoff + (a1_on ? (unsigned)i * sstride : 0u);
-            zs[i] = m4_load16(p.slabs, i < m.ns ? o : 0u); // (runtime shapes: the slots past n_slabs re-read offset 0 and are not summed)
+            if ((TUNE & (1 << 21)) && i > 0) zs[i] = (f32x4){0.001f * (float)i, 0.f, 0.f, 0.f}; // (probe: what twelve of the thirteen slab loads cost)
+            else zs[i] = m4_load16(p.slabs, i < m.ns ? o : 0u); // (runtime shapes: the slots past n_slabs re-read offset 0 and are not summed)
         }
         GNN_RB_STAMP(6); // this wave's phase-0 loads issued
         f32x4 z = zs[0];
@@ -426,6 +428,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
             f32x4 av1[UPW1 > 0 ? UPW1 : 1];
 #pragma unroll
             for (int uu = 0; uu < UPW1; uu++) av1[uu] = *reinterpret_cast<const f32x4 *>(arow + 8 * (u0 + (uu < nu ? uu : 0)));
+            if (STAMP) { asm volatile("" : "+v"(av1[UPW1 > 0 ? UPW1 - 1 : 0])); GNN_RB_WSTAMP(5); } // A operands here
             // software pipeline over the wave's units: request unit uu + RB_PF, multiply unit uu, copy its rows to the LDS
             // image for the backward product (13 cycles of the LDS store path per write, under the matrix pipe's 128 per unit)
 #pragma unroll
@@ -443,6 +446,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                         for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(av1[uu][tt], w1[uu][tt][j], acc[j], 0, 0, 0);
                     if (!(EARLY_IMG && uu < PF0) && (!DEFER || wave < n_sum_waves)) to_image_1(uu);
                 }
+                if (STAMP && uu == 1) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); GNN_RB_WSTAMP(6); } // units 0, 1 multiplied
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -463,18 +467,31 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                     if (ub + uu < nu) { unit(u0 + ub + uu, w[uu]); to_image(u0 + ub + uu, w[uu]); }
             }
         }
-        if (STAMP) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); GNN_RB_STAMP(8); } // MFMAs + image writes issued, results in
+        if (STAMP) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); GNN_RB_STAMP(8); if (l == 1) GNN_RB_WSTAMP(7); } // MFMAs + image writes issued, results in
         if (l == 1 && y_on) *reinterpret_cast<f32x4 *>(smem + m.off_y + y_r * m.ld[Lm] + y_q * 4) = yv;
-        // the two half-waves sat at different k: add them, then the slice's partial tile, 16 B per row and lane
+        // the two half-waves sat at different k: add them -- one row swap serves TWO values: rows r and r + 2 change halves
+        // (v_permlane32_swap: the upper half of one register against the lower half of the other), after which the lower
+        // half-wave holds the sums (lower + upper, as before) of rows 0 and 1 and the upper one those of rows 2 and 3 -- and each
+        // half writes its two rows of the slice's partial tile, 16 B per row and lane.  (One swap per value and four rows
+        // from the lower half alone took 1 000-1 300 cycles between the last MFMA and the barrier: tools/rowblock_probe.)
+        // (Inline asm: with two DIFFERENT inputs hipcc 7.2 lowered __builtin_amdgcn_permlane32_swap to a swap of the first input
+        //  with a copy of itself -- half the swaps gone, results wrong.  The asm is opaque to the hazard recogniser: the wait
+        //  states between the last MFMA and the first read of its result are supplied here.)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        f32x4 half_sum[2];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int r = 0; r < 2; r++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[j][r] = rb_sum32(acc[j][r]);
+            for (int j = 0; j < 4; j++) {
+                float x = acc[j][r], y = acc[j][r + 2];
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); // x = (x.lower, y.lower), y = (x.upper, y.upper)
+                half_sum[r][j] = x + y;
+            }
         if (l == 1) GNN_RB_WSTAMP(1); // this wave's MFMAs done
-        if (hq == 0 && lane_on) {
-            float *part = smem + m.off_scratch + (s * 4) * N + col;
+        if (lane_on) {
+            float *part = smem + m.off_scratch + (s * 4 + 2 * hq) * N + col;
 #pragma unroll
-            for (int r = 0; r < 4; r++) *reinterpret_cast<f32x4 *>(part + r * N) = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+            for (int r = 0; r < 2; r++) *reinterpret_cast<f32x4 *>(part + r * N) = half_sum[r];
         }
         if (l == 1) GNN_RB_WSTAMP(2); // this wave at the partial-tile barrier
         __syncthreads();

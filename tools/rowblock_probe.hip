@@ -90,7 +90,7 @@ int main(int argc, char **argv) {
         CK(hipMemsetAsync(stamps, 0, 4096 * 16 * 8, s));
         hipLaunchKernelGGL(kst, grid, dim3(RB_NT), ldsr, s, rb);
         CK(hipStreamSynchronize(s));
-        std::vector<unsigned long long> hs((size_t)32 * 16 * 6);
+        std::vector<unsigned long long> hs((size_t)32 * 16 * 9);
         CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
         for (int w : {0, 16}) {
             const unsigned long long *q = &hs[w * 16];
@@ -98,8 +98,8 @@ int main(int argc, char **argv) {
                    q[1] - q[0], q[6] - q[0], q[7] - q[0], q[2] - q[1], q[8] - q[1], q[12] - q[2], q[14] - q[12], q[14] - q[0]);
             printf("    tail of wave 0 (from the partial-tile barrier): slices summed +%llu | logits +%llu | k groups reduced +%llu | output rule +%llu | delta_{L-2} operands read +%llu | done +%llu\n",
                    q[3] - q[2], q[9] - q[2], q[10] - q[2], q[11] - q[2], q[5] - q[2], q[4] - q[2]);
-            const char *rn[5] = {"at A1 barrier", "MFMAs done", "at partial barrier", "tail phase end", "done"};
-            for (int r = 0; r < 5; r++) {
+            const char *rn[8] = {"at A1 barrier", "halves summed", "at partial barrier", "tail phase end", "done", "A operands here", "units 0,1 multiplied", "all units multiplied"};
+            for (int r : {0, 5, 6, 7, 1, 2, 3, 4}) {
                 printf("    waves %-18s (from start):", rn[r]);
                 for (int v = 0; v < 8; v++) printf(" %6lld", (long long)(hs[(size_t)(16 * 32) * (1 + r) + w * 16 + v] - q[0]));
                 printf("\n");
@@ -119,6 +119,10 @@ int main(int argc, char **argv) {
     time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, rb); });
     VARIANT(0);   // weights first (2 units), images of waves 4-7 deferred
     VARIANT(128); // image rows of the first units NOT copied before the A_1 barrier
+    VARIANT(0x100000); // NO weight stream (constants instead of W_1's loads; wrong results): what it costs
+    VARIANT(0x200000); // ONE slab load instead of thirteen (wrong results)
+    VARIANT(0x300000); // both
+    VARIANT(0);
     time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
     return 0;
 }
