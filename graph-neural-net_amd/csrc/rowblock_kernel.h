@@ -395,6 +395,30 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     __syncthreads();
     GNN_RB_STAMP(1);
 
+    // The row tail's operands that do not depend on the activations -- the last weight image, once in the logits' layout
+    // (lane (kg, q): rows kg + 16 i, columns 4q..) and once by row (lanes n and n + 64) for delta_{L-2} -- are read by the tail
+    // waves BEFORE the barrier in front of the tail, where they wait anyway: behind it each set was an LDS round trip in the
+    // middle of a lone wave's chain (the image has been complete since the A_1 barrier).
+    constexpr int TK = 8; // K <= 128 = 16 k groups x 8
+    f32x4 tw4[TK], twn[2][4];
+    auto load_tail_weights = [&]() {
+        const float *Wl = smem + m.off_w[Lm - 1];
+        const int K = m.kr[Lm - 1], lwl = m.lw[Lm - 1];
+        const int kg = lane >> 2, q = lane & 3;
+        const bool q_on = 4 * q < m.kr[Lm];
+#pragma unroll
+        for (int i = 0; i < TK; i++) {
+            const int k = kg + 16 * i;
+            tw4[i] = *reinterpret_cast<const f32x4 *>(Wl + ((k < K && q_on) ? k * lwl + 4 * q : 0));
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int n = lane + 64 * half;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) twn[half][qq] = *reinterpret_cast<const f32x4 *>(Wl + ((n < K && 4 * qq < m.kr[Lm]) ? n * lwl + 4 * qq : 0));
+        }
+    };
+
     // ---- forward: layers 2 .. L-2 from registers (SCE:172-194) ---------------------------------------------------------
 #pragma unroll
     for (int l = 1; l < MAX_LAYERS - 2; l++) {
@@ -493,6 +517,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 #pragma unroll
             for (int r = 0; r < 2; r++) *reinterpret_cast<f32x4 *>(part + r * N) = half_sum[r];
         }
+        if (l + 1 == Lm - 1 && wave < 4) load_tail_weights(); // (wave-uniform)
         if (l == 1) GNN_RB_WSTAMP(2); // this wave at the partial-tile barrier
         __syncthreads();
         GNN_RB_STAMP(2 * l);
@@ -552,24 +577,27 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
             GNN_RB_STAMP(3); // this row's slices summed
         }
         const float *a = smem + m.off_act[Lm - 1] + r * (ldp + 4);
-        const float *Wl = smem + m.off_w[Lm - 1];
         const int kg = lane >> 2, q = lane & 3;
         const bool q_on = 4 * q < m.kr[Lm];        // (the image holds kr[Lm] <= 16 columns)
-        constexpr int TK = 8;                      // K <= 128 = 16 k groups x 8
-        f32x4 w4[TK];
+        if (Lm < 3) load_tail_weights();           // (no register product, no barrier in front of the tail: read here)
         float av[TK];
 #pragma unroll
         for (int i = 0; i < TK; i++) {
             const int k = kg + 16 * i;
-            const bool on = k < K && q_on;
-            w4[i] = *reinterpret_cast<const f32x4 *>(Wl + (on ? k * lwl + 4 * q : 0));
-            av[i] = on ? a[k] : 0.f;
+            av[i] = (k < K && q_on) ? a[k] : 0.f;
+        }
+        // (for delta_{L-2}, far below: this lane's two activations -- or, BF, the parked f' -- read now, in the same LDS round trip)
+        float an[2];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int n = lane + 64 * half;
+            an[half] = BF ? smem[((Lm - 1 > 1) ? m.off_dl[Lm - 1] : m.off_fp1) + r * (ldp + 4) + (n < ldp ? n : 0)] : a[n < ldp ? n : 0];
         }
         f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < TK; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) z4[j] = __builtin_fmaf(av[i], w4[i][j], z4[j]);
+            for (int j = 0; j < 4; j++) z4[j] = __builtin_fmaf(av[i], tw4[i][j], z4[j]);
         if (STAMP) { asm volatile("" : "+v"(z4)); GNN_RB_STAMP(9); } // logits: reads + FMAs
 #pragma unroll
         for (int j = 0; j < 4; j++) { // the 16 k groups: lanes q, q+4, q+8, q+12 of every row of 16, then the four rows
@@ -675,19 +703,10 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         {
             // delta_{L-2}[n] = (sum_c delta_{L-1}[c] W[n][c]) f'(a[n]): lane n and n + 64, both halves' reads in flight together;
             // the wave reads back its own 16 deltas (LDS keeps a wave's accesses in order); only the copied columns of W are used
-            f32x4 d4[4], wn[2][4];
-            float an[2];
+            f32x4 d4[4];
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) d4[qq] = *reinterpret_cast<const f32x4 *>(dlast + 4 * qq);
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int n = lane + 64 * half;
-                const bool on = n < K;
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) wn[half][qq] = *reinterpret_cast<const f32x4 *>(Wl + ((on && 4 * qq < m.kr[Lm]) ? n * lwl + 4 * qq : 0));
-                an[half] = a[n < ldp ? n : 0];
-            }
-            if (STAMP) { asm volatile("" : "+v"(wn[1][3]), "+v"(an[1])); GNN_RB_STAMP(5); } // delta_{L-2}'s operands read
+            if (STAMP) { asm volatile("" : "+v"(d4[3])); GNN_RB_STAMP(5); } // delta_{L-2}'s operands read
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const int n = lane + 64 * half;
@@ -698,11 +717,11 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                         for (int qq = 0; qq < 4; qq++)
                             if (4 * qq < m.kr[Lm])
 #pragma unroll
-                                for (int j = 0; j < 4; j++) accd = __builtin_fmaf(d4[qq][j], wn[half][qq][j], accd);
+                                for (int j = 0; j < 4; j++) accd = __builtin_fmaf(d4[qq][j], twn[half][qq][j], accd);
                     }
                     // (BF: f' of the unrounded activation was parked by the forward pass -- in delta_{L-2}'s own slot, or in the
                     //  f'(a_1) image when layer L-2 is layer 1)
-                    const float fpv = BF ? smem[((Lm - 1 > 1) ? m.off_dl[Lm - 1] : m.off_fp1) + r * (ldp + 4) + n] : act_prime_from_a(ACT, an[half]);
+                    const float fpv = BF ? an[half] : act_prime_from_a(ACT, an[half]);
                     const float v = (row < p.B && n < m.d[Lm - 1]) ? accd * fpv : 0.f;
                     if (Lm - 1 > 1) smem[m.off_dl[Lm - 1] + r * (ldp + 4) + n] = opv(v);
                     if (BF) p.deltab[Lm - 1][(size_t)row * ldp + n] = (__bf16)v;
