@@ -397,8 +397,9 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 
     // The row tail's operands that do not depend on the activations -- the last weight image, once in the logits' layout
     // (lane (kg, q): rows kg + 16 i, columns 4q..) and once by row (lanes n and n + 64) for delta_{L-2} -- are read by the tail
-    // waves BEFORE the barrier in front of the tail, where they wait anyway: behind it each set was an LDS round trip in the
-    // middle of a lone wave's chain (the image has been complete since the A_1 barrier).
+    // waves at the START of the register product in front of the tail (right in front of the tail's barrier they delayed it:
+    // a barrier waits for the wave's LDS reads): behind the barrier each set was an LDS round trip in the middle of a lone
+    // wave's chain (the image has been complete since the A_1 barrier).
     constexpr int TK = 8; // K <= 128 = 16 k groups x 8
     f32x4 tw4[TK], twn[2][4];
     auto load_tail_weights = [&]() {
@@ -453,6 +454,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 #pragma unroll
             for (int uu = 0; uu < UPW1; uu++) av1[uu] = *reinterpret_cast<const f32x4 *>(arow + 8 * (u0 + (uu < nu ? uu : 0)));
             if (STAMP) { asm volatile("" : "+v"(av1[UPW1 > 0 ? UPW1 - 1 : 0])); GNN_RB_WSTAMP(5); } // A operands here
+            if (l + 1 == Lm - 1 && wave < 4) load_tail_weights(); // (wave-uniform; see there: LDS has nothing else to do here)
             // software pipeline over the wave's units: request unit uu + RB_PF, multiply unit uu, copy its rows to the LDS
             // image for the backward product (13 cycles of the LDS store path per write, under the matrix pipe's 128 per unit)
 #pragma unroll
@@ -474,6 +476,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
+            if (l + 1 == Lm - 1 && wave < 4) load_tail_weights(); // (as in the branch above)
             // later layers (nets of five and more layers): the slice is loaded here, RB_MAXU units at a time
             for (int ub = 0; ub < nu; ub += RB_MAXU) {
                 f32x4 w[RB_MAXU][4];
@@ -517,7 +520,6 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 #pragma unroll
             for (int r = 0; r < 2; r++) *reinterpret_cast<f32x4 *>(part + r * N) = half_sum[r];
         }
-        if (l + 1 == Lm - 1 && wave < 4) load_tail_weights(); // (wave-uniform)
         if (l == 1) GNN_RB_WSTAMP(2); // this wave at the partial-tile barrier
         __syncthreads();
         GNN_RB_STAMP(2 * l);
@@ -552,7 +554,9 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     if (wave < 4) {
         if (TUNE & 32) __builtin_amdgcn_s_setprio(3); // the four waves on the critical path, over the image copies of the other four
         const int r = wave, row = row0 + r;
-        const int K = m.kr[Lm - 1], nt = m.d[Lm], lwl = m.lw[Lm - 1], ldp = m.ld[Lm - 1];
+        const int K = m.kr[Lm - 1], nt = m.d[Lm], ldp = m.ld[Lm - 1];
+        // (the expected row: requested first, used ~2 000 cycles from here)
+        const f32x4 y4 = (row < p.B && p.Y) ? *reinterpret_cast<const f32x4 *>(smem + m.off_y + r * 16 + 4 * (lane & 3)) : (f32x4){0.f, 0.f, 0.f, 0.f};
         if (Lm >= 3) {
             // this row of the last hidden layer: K slices summed in slice order, f applied (N <= 128: one float4 per lane)
             const int l = Lm - 2, N = ldp, KS = m.ksf[l], n = 4 * lane;
@@ -611,7 +615,6 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         if (STAMP) { asm volatile("" : "+v"(z4)); GNN_RB_STAMP(10); } // k groups reduced
         // output rule on the quad: lane q holds classes 4q..4q+3
         constexpr int QX1 = 0xB1, QX2 = 0x4E; // quad_perm [1,0,3,2] / [2,3,0,1]
-        const f32x4 y4 = (row < p.B && p.Y) ? *reinterpret_cast<const f32x4 *>(smem + m.off_y + r * 16 + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 out4 = {0.f, 0.f, 0.f, 0.f}, dd4 = {0.f, 0.f, 0.f, 0.f};
         float lsum = 0.f, mx = -__builtin_inff(), nan_flag = 0.f;
         int best = -1;
@@ -632,16 +635,22 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         };
         // (selects, not branches: every `if` on a lane value here became a save-exec region with its own waits)
         if (OUTK == 0) {
+            if (p.label) { // (kernel argument: a scalar branch)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float zj = z4[j];
-                nan_flag = (valid[j] & (zj != zj)) ? 1.f : nan_flag;      // any NaN logit -> label 0 (see output_layer_kernel)
-                const bool take = valid[j] & (zj >= mx);                  // `>=`: ties -> the higher index
-                mx = take ? zj : mx;
-                best = take ? 4 * q + j : best;
+                for (int j = 0; j < 4; j++) {
+                    const float zj = z4[j];
+                    nan_flag = (valid[j] & (zj != zj)) ? 1.f : nan_flag;      // any NaN logit -> label 0 (see output_layer_kernel)
+                    const bool take = valid[j] & (zj >= mx);                  // `>=`: ties -> the higher index
+                    mx = take ? zj : mx;
+                    best = take ? 4 * q + j : best;
+                }
+                quad_argmax(mx, best);
+            } else { // (no label asked for, every training step: the maximum as a tree -- NaNs drop out of fmaxf as they do out of `>=`)
+                const float m01 = fmaxf(valid[0] ? z4[0] : -__builtin_inff(), valid[1] ? z4[1] : -__builtin_inff());
+                const float m23 = fmaxf(valid[2] ? z4[2] : -__builtin_inff(), valid[3] ? z4[3] : -__builtin_inff());
+                mx = fmaxf(m01, m23);
+                mx = fmaxf(mx, dpp_f<QX1>(mx)); mx = fmaxf(mx, dpp_f<QX2>(mx));
             }
-            if (p.label) quad_argmax(mx, best);
-            else { mx = fmaxf(mx, dpp_f<QX1>(mx)); mx = fmaxf(mx, dpp_f<QX2>(mx)); }
             f32x4 e4;
             float ssum = 0.f;
 #pragma unroll
@@ -755,6 +764,10 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
             const int n = g * 64 + lane;
             const float *arow = smem + m.off_dl[l + 1] + (lane & 3) * (m.ld[l + 1] + 4);
             const float *wp = smem + m.off_w[l] + (n < NR ? n : NR - 1) * m.lw[l]; // columns past the image compute garbage nobody stores
+            // (the epilogue's operand -- f'(z_l) from a_l, or the parked f' -- requested in front of the product)
+            float alr[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) alr[r] = smem[(BF ? (l > 1 ? m.off_dl[l] : m.off_fp1) : m.off_act[l]) + r * (N + 4) + (n < N ? n : 0)];
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             constexpr int U = 4;
             int kb = 0;
@@ -780,7 +793,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     // f'(z_l) from a_l = f(z_l); BF: parked by the forward pass (from the unrounded a_l) in delta_l's slot / the f'(a_1) image
-                    const float al = smem[(BF ? (l > 1 ? m.off_dl[l] : m.off_fp1) : m.off_act[l]) + r * (N + 4) + n];
+                    const float al = alr[r];
                     const float v = (row0 + r < p.B && n < m.d[l]) ? acc[r] * (BF ? al : act_prime_from_a(ACT, al)) : 0.f;
                     if (BF) p.deltab[l][(size_t)(row0 + r) * N + n] = (__bf16)v;
                     else p.delta[l][(size_t)(row0 + r) * N + n] = v;
