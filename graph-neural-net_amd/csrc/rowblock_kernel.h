@@ -511,7 +511,9 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float x = acc[j][r], y = acc[j][r + 2];
-                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); // x = (x.lower, y.lower), y = (x.upper, y.upper)
+                // x = (x.lower, y.lower), y = (x.upper, y.upper).  (s_nop 1: the two wait states between a vector instruction that
+                //  writes a register -- the compiler may copy x or y right in front of this statement -- and a swap that reads it.)
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
                 half_sum[r][j] = x + y;
             }
         if (l == 1) GNN_RB_WSTAMP(1); // this wave's MFMAs done

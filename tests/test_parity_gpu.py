@@ -780,3 +780,26 @@ def test_runtime_specialisation_is_bitwise_identical(gnn):
     assert c.specialization == 1 and c.rowblock_state == 2
     a.train_range(0, B, 64, 0.0125, 0.9)
     assert a.specialization == 2
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_long_runs_repeat_bitwise(gnn, dtype_name):
+    """Two handles, the same seed, the same 4 000 steps over 16 resident batches: bitwise equal weights -- and once more
+    after another 4 000.  The two-launch step's kernels hold inline-asm statements (write-through stores, row swaps)
+    whose wait states the compiler cannot check; when one was missing (the bf16 tile kernel's slab store, round 3) the
+    results were wrong DIFFERENTLY on every run, which is what this test looks for."""
+    dims, B, nb = [784, 300, 100, 10], 128, 16
+    dtype = gnn.DTYPE_BF16 if dtype_name == "bf16" else gnn.DTYPE_F32
+    X, Y = make_batch(dims, B * nb, seed=5, sparse=True)
+    nets = [gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B, dtype=dtype) for _ in range(2)]
+    w0 = nets[0].get_weights() * 0.2
+    for n in nets:
+        n.set_weights(w0)
+        n.upload_dataset(X, Y)
+    for rounds in range(2):
+        for n in nets:
+            n.train_range(0, B, 4000, 0.0125, 0.9)
+        w = [n.get_weights() for n in nets]
+        assert np.isfinite(w[0]).all()
+        assert np.array_equal(w[0], w[1])
+    assert nets[0].step_launches == 2
