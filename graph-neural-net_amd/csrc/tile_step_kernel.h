@@ -302,6 +302,8 @@ __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
     }
     if (GSRC >= 2) g_in = ts_gradient_in<GSRC>(p, L, e_off, e_ok);
     const bool next_plain = interior && fwd && !p.next_idx && p.next_rows >= TS_KC && (unsigned long long)TS_KC * (unsigned)p.ldan < 0xffffffffull; // the first chunk of the next batch: all rows live, in place
+    const bool next_gather = (m0 + TS_TM <= L.M) && fwd && p.next_idx && p.next_rows >= TS_KC;
+    const int stage_cols = (L.N / TS_TN) < 8 ? (L.N / TS_TN) : 8; // tile columns that share the staging copy's 16-row groups
     // the next batch's rows, already in MFMA fragment form: wave -> 16 batch rows of a 128-row chunk, lane
     // (fr, fq) -> row fr, inputs 16c + 4fq .. +3 of the tile (c = 0..3).  Straight to registers: A_0' is
     // k-contiguous, no wave shares another's rows, and the product below needs no LDS image of it.
@@ -320,6 +322,13 @@ __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
             const int b = b0 + (wave + g * NW) * 16 + fr;
             if (b0 == 0 && next_plain) { // (block-uniform)
                 const float *src = p.An + ((unsigned)b * (unsigned)p.ldan + m0 + 4 * fq);
+#pragma unroll
+                for (int c = 0; c < 4; c++) vn[g][c] = *reinterpret_cast<const f32x4 *>(src + c * 16);
+                continue;
+            }
+            if (b0 == 0 && next_gather) { // (block-uniform) a sampled batch, every row live, the tile inside the layer: the same
+                                          // four loads from the row the index names (fetched at the top), no bounds tests
+                const float *src = p.An + ((size_t)next_row0[g] * p.ldan + m0 + 4 * fq);
 #pragma unroll
                 for (int c = 0; c < 4; c++) vn[g][c] = *reinterpret_cast<const f32x4 *>(src + c * 16);
                 continue;
@@ -468,7 +477,9 @@ __global__ __launch_bounds__(NW * 64) void tile_step_kernel(TileStepParams p) {
 #pragma unroll
         for (int g = 0; g < RPW; g++) {
             const int wr = (wave + g * NW) * 16; // this wave's row group of the chunk
-            if (p.stage_out && tn == 0 && b0 + wr < p.next_K) { // (rows past the batch and columns past M are zeros in vn)
+            // the contiguous copy of a sampled next batch: every tile of this tile row holds the same rows; column tn copies
+            // the 16-row groups g16 with g16 % n_tn == tn (all of them in one column made its 13 workgroups the kernel's last)
+            if (p.stage_out && b0 + wr < p.next_K && (((b0 + wr) >> 4) % stage_cols) == tn % stage_cols && tn < stage_cols) { // (wave-uniform; rows past the batch and columns past M are zeros in vn)
                 float *dst = p.stage_out + (size_t)(b0 + wr + fr) * p.ldan + m0 + 4 * fq;
 #pragma unroll
                 for (int c = 0; c < 4; c++)
@@ -530,6 +541,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
     const int m0 = tm * TS_TM, n0 = tn * TS_TN;
     const bool fwd = FWD && li == 0;
     const __bf16 *Ab = p.Ab[li], *Db = p.Db[li];
+    const int stage_cols = (L.N / TS_TN) < 8 ? (L.N / TS_TN) : 8; // tile columns that share the staging copy's 16-row groups
 
     const int er = (t >> 6) * 16 + fr, eq = fg; // (as in tile_step_kernel: the accumulator layout of the transposed product)
     const bool e_ok = t < 256 && (m0 + er < L.M);
@@ -638,7 +650,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_step_bf16_kernel(TileStepPara
     const bf16x8 w0 = tr_frag(sW, TS_TN, 0, 0, lane), w1 = tr_frag(sW, TS_TN, 0, 32, lane); // A operand: rows n, k = m
     for (int b0 = 0; b0 < p.next_K; b0 += TS_KC) {
         if (b0) load_next(b0);
-        if (p.stage_out_b && tn == 0 && b0 + wave * 16 < p.next_K) {
+        if (p.stage_out_b && tn < stage_cols && (((b0 + wave * 16) >> 4) % stage_cols) == tn && b0 + wave * 16 < p.next_K) { // (as in tile_step_kernel)
             __bf16 *dst = p.stage_out_b + (size_t)(b0 + wave * 16 + fr) * p.ldan + m0 + 4 * fg;
 #pragma unroll
             for (int kb = 0; kb < 2; kb++)
