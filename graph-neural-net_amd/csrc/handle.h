@@ -267,7 +267,7 @@ void plan_mid4(gnn_mlp *h);
 void plan_rowblock(gnn_mlp *h); // (after plan_chain: the kernel exists for the two-launch step only)
 void try_specialize(gnn_mlp *h);
 void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
-                   bool want_loss, bool want_label, bool from_slabs = false);
+                   bool want_loss, bool want_label, bool from_slabs = false, bool copy_rows = false);
 void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, const float *a0, int B, float step_over_b, float momentum,
                       bool staged = false, const PeerGradients *peers = nullptr);
 

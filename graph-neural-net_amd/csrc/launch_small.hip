@@ -175,7 +175,7 @@ void try_specialize(gnn_mlp *h) {
 // forward of the middle4 path; backward = also delta_1..delta_{L-1}
 // from_slabs: A_1 = f(sum of the K slabs) (tile_step_kernel made them); else fwd_first_kernel writes act[1] first
 void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
-                   bool want_loss, bool want_label, bool from_slabs) {
+                   bool want_loss, bool want_label, bool from_slabs, bool copy_rows) {
     if (!from_slabs) launch_fwd_first(h, a0, B);
     if (from_slabs && h->rb) { // the two-launch step's training kernel (rowblock_kernel.h)
         RbParams r = h->rbp;
@@ -186,6 +186,11 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
         r.label = want_label ? h->labels : nullptr;
         r.B = B;
         r.row_idx = h->cur_idx;
+        if (copy_rows && h->cur_idx) { // the sampled batch's rows, contiguous, for the tile kernel that follows (RbParams::xcopy)
+            r.ldx = h->ld[0];
+            if (h->dtype == GNN_DTYPE_BF16) { r.Xb = a0_bf16(h, a0); r.xcopyb = h->xstage_b[h->xstage_cur]; }
+            else { r.X = a0; r.xcopy = h->xstage[h->xstage_cur]; }
+        }
         void *args[] = {&r};
         const unsigned grid = (unsigned)(pad_up(B) / 4);
         TimerClass &tc = h->timers[GNN_K_MIDDLE];
@@ -256,7 +261,7 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
     t.K = pad_up(B); t.k_true = B;
     t.row_idx = staged ? nullptr : h->cur_idx;
     const int stage_dst = h->xstage_cur ^ 1; // a sampled next batch is copied to the OTHER buffer (this launch may be reading the current one)
-    if (next && next->idx) { t.stage_out = h->xstage[stage_dst]; t.stage_out_b = h->xstage_b[stage_dst]; }
+    if (next && next->idx && !h->rb) { t.stage_out = h->xstage[stage_dst]; t.stage_out_b = h->xstage_b[stage_dst]; } // (with the row-block kernel on the path IT makes the copy)
     t.step_over_b = step_over_b; t.momentum = momentum;
     const bool fwd = next != nullptr;
     if (fwd) { t.An = next->a0; t.ldan = h->ld[0]; t.next_idx = next->idx; t.next_rows = next->B; t.next_K = pad_up(next->B); }

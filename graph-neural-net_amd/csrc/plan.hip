@@ -155,6 +155,7 @@ bool take_next(gnn_mlp *h, NextBatch *nb) {
 }
 // staged_copy: the launch that made these slabs also wrote the batch's rows to the other staging buffer
 void slabs_now_hold(gnn_mlp *h, const NextBatch &nb, bool staged_copy) {
+    if (h->rb) staged_copy = false; // (on the row-block kernel's path the tile kernel writes no copy: that kernel does, for its own batch)
     h->slab_valid = true; h->slab_a0 = nb.a0; h->slab_idx = nb.idx; h->slab_B = nb.B;
     if (staged_copy) h->xstage_cur ^= 1;
     h->xstage_valid = staged_copy;
@@ -168,9 +169,10 @@ void chain_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fus
         launch_tile_step(h, 0, 0, &self, a0, B, 0.f, 0.f); // chain start: the slabs of this batch from the weights as they are
         slabs_now_hold(h, self, self.idx != nullptr);
     }
-    const bool staged = h->xstage_valid && h->cur_idx != nullptr; // the launch that made the slabs left a contiguous copy of these rows
+    const bool rb_copy = h->rb && h->cur_idx != nullptr; // a sampled batch on the row-block kernel's path: that kernel leaves the contiguous copy
+    const bool staged = rb_copy || (h->xstage_valid && h->cur_idx != nullptr); // (else: the tile launch that made the slabs did)
     h->slab_valid = false;
-    fused_forward(h, a0, y, B, true, false, false, false, true);
+    fused_forward(h, a0, y, B, true, false, false, false, true, rb_copy);
     NextBatch nb{};
     if (fused_update) {
         const bool fwd = take_next(h, &nb);

@@ -124,6 +124,11 @@ struct RbParams {
     const __bf16 *Wb[MAX_LAYERS];
     __bf16 *actb[MAX_LAYERS];
     __bf16 *deltab[MAX_LAYERS];
+    // A SAMPLED batch (row_idx != null): the four input rows of this row block, gathered from the data set, are also written
+    // to a contiguous copy [padded batch rows][ldx] by waves 4..7 while the row tail runs -- the tile kernel that follows reads
+    // its gradient operand A_0 from the copy with plain addressing (the same copy written by the PREVIOUS tile kernel cost it
+    // 0.8 us: tools/tile_probe).  Null = no copy.
+    const float *X; float *xcopy; const __bf16 *Xb; __bf16 *xcopyb; int ldx;
 };
 
 // four bf16 weights (8 B of the shadow) widened to the f32 values they stand for
@@ -268,6 +273,9 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     const bool y_on = p.Y != nullptr && y_e < 4 * qy;
     const bool y_ix = y_on && p.row_idx != nullptr && row0 + y_r < p.B;
     const int y_ld = *(y_ix ? p.row_idx + (row0 + y_r) : reinterpret_cast<const int32_t *>(p.slabs));
+    // (waves 4..7 copy one input row each of a sampled batch during the row tail: its index, same way)
+    const bool x_ix = p.row_idx != nullptr && wave >= 4 && row0 + (wave - 4) < p.B;
+    const int x_ld = *(x_ix ? p.row_idx + (row0 + wave - 4) : reinterpret_cast<const int32_t *>(p.slabs));
     // the last weight image (the row tail reads it from LDS): one small load
     const int c4l = m.kr[Lm] >> 2, nl4 = m.kr[Lm - 1] * c4l; // float4s of the last image's logical columns (<= 128 * 4)
     const int wl_r = IS_STATIC ? t / c4l : (int)(((unsigned)t * (((1u << 22) + c4l - 1) / c4l)) >> 22), wl_c = t - wl_r * c4l;
@@ -745,6 +753,39 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 #pragma unroll
         for (int uu = 0; uu < UPW1; uu++)
             if (!(EARLY_IMG && uu < PF0) && uu < nu_1) to_image_1(uu);
+    }
+    if (wave >= 4 && p.row_idx && (p.xcopy || p.xcopyb)) { // (wave-uniform) wave 4 + r: input row r of this block
+        // (the row's index was fetched at the top; every load of the row in flight before the first store: as a loop of
+        //  load - wait - store the copy took as long as the row tail and held up the barrier behind it)
+        const int r = wave - 4, row = row0 + r;
+        const bool live = row < p.B;
+        const size_t src = live ? (size_t)x_ld * p.ldx : 0, dst = (size_t)row * p.ldx;
+        constexpr int XC = 4; // 4 x 64 lanes x 4 elements = 1024 columns
+        if (p.xcopy) {
+            f32x4 v[XC];
+#pragma unroll
+            for (int i = 0; i < XC; i++) {
+                const int c = 4 * lane + 256 * i;
+                v[i] = *reinterpret_cast<const f32x4 *>(p.X + src + (c < p.ldx ? c : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < XC; i++) {
+                const int c = 4 * lane + 256 * i;
+                if (c < p.ldx) *reinterpret_cast<f32x4 *>(p.xcopy + dst + c) = live ? v[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            uint2 v[XC];
+#pragma unroll
+            for (int i = 0; i < XC; i++) {
+                const int c = 4 * lane + 256 * i;
+                v[i] = *reinterpret_cast<const uint2 *>(p.Xb + src + (c < p.ldx ? c : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < XC; i++) {
+                const int c = 4 * lane + 256 * i;
+                if (c < p.ldx) *reinterpret_cast<uint2 *>(p.xcopyb + dst + c) = live ? v[i] : make_uint2(0u, 0u);
+            }
+        }
     }
     if (TUNE & 32) __builtin_amdgcn_s_setprio(0);
     GNN_RB_STAMP(4);  // wave 0's tail done

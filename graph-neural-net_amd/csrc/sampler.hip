@@ -129,29 +129,51 @@ int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int ba
             if (t.joinable()) t.join();
         }
     } joiner{producer, sh};
+    std::vector<int> dcnt((size_t)kRing * kChunk, 0); // the batch sizes of the chunks on the device (the host ring is the sampler's again by then)
     DevScratch dbuf;
     int rc = dbuf.alloc(slot_elems * kRing * sizeof(int32_t));
     int32_t *d_idx = dbuf.as<int32_t>();
+    // Chunk c + 1's draws go to the device ring BEFORE chunk c's steps are enqueued (when the sampler has them, which it has:
+    // it runs kRing chunks ahead): the last step of a chunk then knows its successor like every other step, and the chain of
+    // two-launch steps runs through the chunk boundary -- an upload in stream order at the boundary left the GPU idle for
+    // the copy and restarted the chain with a forward-only launch, ~1 us per step over a run.
+    int uploaded = 0; // chunks whose draws are on the device (or in flight in front of every launch that reads them)
+    auto upload = [&](int c) -> int {
+        const int j0 = chunk_begin(c), j1 = chunk_end(c);
+        const size_t so = (size_t)(c % kRing) * slot_elems;
+        // (pageable hipMemcpyAsync returns once the host data has been consumed: the host slot is then free for the sampler.  The
+        //  counts are copied out of the ring first: the sampler may refill the host slot from here on.)
+        std::copy(cnt.begin() + (size_t)(c % kRing) * kChunk, cnt.begin() + (size_t)(c % kRing) * kChunk + (j1 - j0), dcnt.begin() + (size_t)(c % kRing) * kChunk);
+        const hipError_t e = hipMemcpyAsync(d_idx + so, idx.data() + so, (size_t)(j1 - j0) * batch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) return fail(GNN_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+        { std::lock_guard<std::mutex> lk(sh.mu); sh.consumed = c + 1; }
+        sh.cv.notify_all();
+        uploaded = c + 1;
+        return GNN_OK;
+    };
     for (int c = 0; c < n_chunks && rc == GNN_OK; c++) {
-        {
+        if (uploaded <= c) {
             std::unique_lock<std::mutex> lk(sh.mu);
             sh.cv.wait(lk, [&] { return sh.ready > c; });
             if (sh.sampler_rc != GNN_OK) { rc = fail(sh.sampler_rc, sh.sampler_msg); break; }
+            lk.unlock();
+            rc = upload(c);
+            if (rc != GNN_OK) break;
+        }
+        if (c + 1 < n_chunks) { // the successor too, if it is drawn already (no waiting for it)
+            bool have = false;
+            { std::lock_guard<std::mutex> lk(sh.mu); have = sh.ready > c + 1 && sh.sampler_rc == GNN_OK; }
+            if (have) { rc = upload(c + 1); if (rc != GNN_OK) break; }
         }
         const int i0 = chunk_begin(c), i1 = chunk_end(c);
         const size_t so = (size_t)(c % kRing) * slot_elems;
-        std::vector<int> ccnt(cnt.begin() + (size_t)(c % kRing) * kChunk, cnt.begin() + (size_t)(c % kRing) * kChunk + (i1 - i0));
-        // (pageable hipMemcpyAsync returns once the host data has been consumed: the host slot is then free for the sampler)
-        const hipError_t e = hipMemcpyAsync(d_idx + so, idx.data() + so, (size_t)(i1 - i0) * batch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
-        if (e != hipSuccess) { rc = fail(GNN_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); break; }
-        {
-            std::lock_guard<std::mutex> lk(sh.mu);
-            sh.consumed = c + 1;
-        }
-        sh.cv.notify_all();
+        const int *ccnt = dcnt.data() + (size_t)(c % kRing) * kChunk;
         for (int i = i0; i < i1 && rc == GNN_OK; i++) {
             if (h->chain && i + 1 < i1) { // the next draw of this chunk is already on the device
                 h->have_next = true; h->next_a0 = h->DX; h->next_idx = d_idx + so + (size_t)(i + 1 - i0) * batch; h->next_B = ccnt[i + 1 - i0];
+            } else if (h->chain && uploaded > c + 1) { // ... and so is the first draw of the next chunk
+                const size_t sn = (size_t)((c + 1) % kRing) * slot_elems;
+                h->have_next = true; h->next_a0 = h->DX; h->next_idx = d_idx + sn; h->next_B = dcnt[(size_t)((c + 1) % kRing) * kChunk];
             }
             rc = step_on_device_indices(h, d_idx + so + (size_t)(i - i0) * batch, ccnt[i - i0], step, momentum);
         }

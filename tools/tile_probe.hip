@@ -95,6 +95,21 @@ int main(int argc, char **argv) {
         time_it("pair: tile_step + dependent fwd-only launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; u.map_in_args = pack_tile_map(hm0, u.map_words) ? 1 : 0; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
         time_it("pair: tile_step (write-through 2) + dependent launch", 300, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 8, 2>), dim3(tiles), dim3(TS_THREADS), 0, s, t); TileStepParams u = t; u.n_layers = 1; u.tile_map = map0_new; u.map_in_args = pack_tile_map(hm0, u.map_words) ? 1 : 0; hipLaunchKernelGGL((tile_step_kernel<0, 0, true>), dim3(tiles0), dim3(TS_THREADS), 0, s, u); });
     }
+    {   // a SAMPLED next batch: rows gathered through an index vector from a 6 000-row data set, with and without the contiguous copy
+        const int NR = 6000;
+        float *big; CK(hipMalloc(&big, (size_t)NR * ld[0] * 4)); CK(hipMemset(big, 0, (size_t)NR * ld[0] * 4));
+        std::vector<int32_t> hidx(Bp); for (int i = 0; i < Bp; i++) hidx[i] = rand() % NR;
+        int32_t *didx; CK(hipMalloc(&didx, Bp * 4)); CK(hipMemcpy(didx, hidx.data(), Bp * 4, hipMemcpyHostToDevice));
+        float *copy; CK(hipMalloc(&copy, (size_t)Bp * ld[0] * 4));
+        TileStepParams g = t; g.An = big; g.next_idx = didx;
+        TileStepParams gc = g; gc.stage_out = copy;
+        TileStepParams seq = t; seq.An = big; // the same data set, rows in place
+        for (int rep = 0; rep < 2; rep++) {
+            time_it("next batch in place (6 000-row set)", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, seq); });
+            time_it("next batch gathered by index", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, g); });
+            time_it("next batch gathered + contiguous copy written", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true>), dim3(tiles), dim3(TS_THREADS), 0, s, gc); });
+        }
+    }
     time_it("tile_step<grad, update, fwd> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
     time_it("tile_step<grad, update, fwd> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 2, true, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
     time_it("tile_step<grad, store G> 4 waves", 500, [&]() { hipLaunchKernelGGL((tile_step_kernel<1, 1, false, false, 4>), dim3(tiles), dim3(256), 0, s, t); });
