@@ -410,8 +410,11 @@ def test_graph_replay_between_eager_steps_with_hints(gnn):
     does not hold (two-launch path: the first-layer sums made AHEAD for the next batch).  bench.py's shape: a warm run
     that does not end on the graph's first batch, replays, then eager steps on another batch -- all with next-batch
     hints -- against the same steps run all-eager.  The chain may be cut anywhere without changing a bit."""
+    import os
     import torch
     from gnn_amd import data_parallel as dp
+    if os.environ.get("GNN_MLP_PATH") or os.environ.get("GNN_MLP_CHAIN") == "0":
+        pytest.skip("path forced by the environment")
     dims, B, nb = [784, 300, 100, 10], 128, 6
     X, Y = make_batch(dims, B * nb, seed=22)
     firsts = [b * B for b in range(nb)]
@@ -758,7 +761,8 @@ def test_runtime_specialisation_is_bitwise_identical(gnn):
     """gnn_mlp_specialize (hiprtc instantiation of the fused path's kernel template for this
     net's layer sizes) changes speed only: same arithmetic, same order, bitwise equal results."""
     import os
-    if os.environ.get("GNN_MLP_PATH") or os.environ.get("GNN_MLP_JIT") == "0" or os.environ.get("GNN_MLP_STATIC") == "0":
+    if (os.environ.get("GNN_MLP_PATH") or os.environ.get("GNN_MLP_JIT") == "0" or os.environ.get("GNN_MLP_STATIC") == "0"
+            or os.environ.get("GNN_MLP_ROWBLOCK") == "0" or os.environ.get("GNN_MLP_CHAIN") == "0"):
         pytest.skip("path forced by the environment")
     dims, B, nb = [784, 256, 64, 10], 64, 4
     X, Y = make_batch(dims, B * nb, seed=41, sparse=True)
@@ -788,6 +792,8 @@ def test_long_runs_repeat_bitwise(gnn, dtype_name):
     after another 4 000.  The two-launch step's kernels hold inline-asm statements (write-through stores, row swaps)
     whose wait states the compiler cannot check; when one was missing (the bf16 tile kernel's slab store, round 3) the
     results were wrong DIFFERENTLY on every run, which is what this test looks for."""
+    import os
+    forced = bool(os.environ.get("GNN_MLP_PATH")) or os.environ.get("GNN_MLP_CHAIN") == "0"
     dims, B, nb = [784, 300, 100, 10], 128, 16
     dtype = gnn.DTYPE_BF16 if dtype_name == "bf16" else gnn.DTYPE_F32
     X, Y = make_batch(dims, B * nb, seed=5, sparse=True)
@@ -802,4 +808,4 @@ def test_long_runs_repeat_bitwise(gnn, dtype_name):
         w = [n.get_weights() for n in nets]
         assert np.isfinite(w[0]).all()
         assert np.array_equal(w[0], w[1])
-    assert nets[0].step_launches == 2
+    assert forced or nets[0].step_launches == 2
