@@ -119,16 +119,17 @@ struct RbParams {
     int inner_act, last_act;     // inner_act is read only by kernels built with ACT = -1
     const int32_t *row_idx;      // optional: expected row of batch row r is Y row row_idx[r] (sampled batches)
     const float *slabs; int slab_rows; // slab s of batch row b at slabs[(s * slab_rows + b) * ld[1]] (tile_step_kernel.h)
+    // A SAMPLED batch (row_idx != null): the four input rows of this row block, gathered from the data set, are also written
+    // to a contiguous copy [padded batch rows][ldx] by waves 4..7 while the row tail runs -- the tile kernel that follows reads
+    // its gradient operand A_0 from the copy with plain addressing (the same copy written by the PREVIOUS tile kernel cost it
+    // 0.8 us: tools/tile_probe).  Null = no copy.  (Beside row_idx and slabs: the kernel's top reads these fields, and a field
+    // in a kernel-argument cache line of its own is one more scalar-cache miss in front of the first load.)
+    float *xcopy; __bf16 *xcopyb; const float *X; const __bf16 *Xb; int ldx;
     unsigned long long *stamps;  // STAMP builds only: 16 slots per workgroup
     // bf16 kernels (BF): the bf16 shadow of W_l and the bf16 outputs the tile kernel reads, as in Mid4Params
     const __bf16 *Wb[MAX_LAYERS];
     __bf16 *actb[MAX_LAYERS];
     __bf16 *deltab[MAX_LAYERS];
-    // A SAMPLED batch (row_idx != null): the four input rows of this row block, gathered from the data set, are also written
-    // to a contiguous copy [padded batch rows][ldx] by waves 4..7 while the row tail runs -- the tile kernel that follows reads
-    // its gradient operand A_0 from the copy with plain addressing (the same copy written by the PREVIOUS tile kernel cost it
-    // 0.8 us: tools/tile_probe).  Null = no copy.
-    const float *X; float *xcopy; const __bf16 *Xb; __bf16 *xcopyb; int ldx;
 };
 
 // four bf16 weights (8 B of the shadow) widened to the f32 values they stand for
@@ -187,56 +188,6 @@ __device__ __forceinline__ float rb_sum16(float x) {
     return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
 }
 
-// Two tasks of the backward product (delta . W^T from the LDS image, see rowblock_product<true>) interleaved in ONE wave:
-// four independent accumulator chains and the reads of both tasks in flight together -- a lone task is a chain of
-// read - wait - 16 dependent MFMAs per trip, and a wave ran its two tasks one after the other.
-__device__ __forceinline__ void rowblock_backward_pair(const float *A_img, int lda, const float *Wimg, int ldw, int n_rows, int gw, int lane,
-                                                       int kbA, int keA, int n0A, float *partA,
-                                                       bool onB, int kbB, int keB, int n0B, float *partB) {
-    const float *arow = A_img + (lane & 3) * lda;
-    int nA = n0A + lane, nB = n0B + lane;
-    nA = nA < n_rows ? nA : n_rows - 1; // columns past the image compute garbage nobody reads
-    nB = nB < n_rows ? nB : n_rows - 1;
-    const float *wA = Wimg + nA * ldw, *wB = Wimg + nB * ldw;
-    f32x4 accA0 = {0.f, 0.f, 0.f, 0.f}, accA1 = accA0, accB0 = accA0, accB1 = accA0;
-    const int lenA = keA - kbA, lenB = onB ? keB - kbB : 0;
-    const int common = (lenA < lenB ? lenA : lenB) & ~1; // joint trips of two 4-k groups per task: no conditions inside
-    for (int i = 0; i < common; i += 2) { // (bounds are wave-uniform)
-        f32x4 aA[2], bA[2], aB[2], bB[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            aA[u] = *reinterpret_cast<const f32x4 *>(arow + 4 * (kbA + i + u));
-            bA[u] = *reinterpret_cast<const f32x4 *>(wA + 4 * (kbA + i + u));
-            aB[u] = *reinterpret_cast<const f32x4 *>(arow + 4 * (kbB + i + u));
-            bB[u] = *reinterpret_cast<const f32x4 *>(wB + 4 * (kbB + i + u));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            accA0 = __builtin_amdgcn_mfma_f32_4x4x1f32(aA[0][j], bA[0][j], accA0, 0, 0, 0);
-            accB0 = __builtin_amdgcn_mfma_f32_4x4x1f32(aB[0][j], bB[0][j], accB0, 0, 0, 0);
-            accA1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aA[1][j], bA[1][j], accA1, 0, 0, 0);
-            accB1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aB[1][j], bB[1][j], accB1, 0, 0, 0);
-        }
-    }
-    for (int i = common; i < lenA; i++) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 4 * (kbA + i)), b = *reinterpret_cast<const f32x4 *>(wA + 4 * (kbA + i));
-#pragma unroll
-        for (int j = 0; j < 4; j++) accA0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j], b[j], accA0, 0, 0, 0);
-    }
-    for (int i = common; i < lenB; i++) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 4 * (kbB + i)), b = *reinterpret_cast<const f32x4 *>(wB + 4 * (kbB + i));
-#pragma unroll
-        for (int j = 0; j < 4; j++) accB0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j], b[j], accB0, 0, 0, 0);
-    }
-    const f32x4 accA = accA0 + accA1, accB = accB0 + accB1;
-#pragma unroll
-    for (int r = 0; r < 4; r++) partA[r * gw + n0A + lane] = accA[r];
-    if (onB) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) partB[r * gw + n0B + lane] = accB[r];
-    }
-}
-
 // NL > 0: layer count fixed at compile time; IS_STATIC: `m` is a compile-time constant (every extent folds)
 template <int NL, bool IS_STATIC, int ACT_T, int OUTK, bool STAMP, int NSV, int UPW1, int TUNE, bool BF>
 __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
@@ -273,9 +224,6 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     const bool y_on = p.Y != nullptr && y_e < 4 * qy;
     const bool y_ix = y_on && p.row_idx != nullptr && row0 + y_r < p.B;
     const int y_ld = *(y_ix ? p.row_idx + (row0 + y_r) : reinterpret_cast<const int32_t *>(p.slabs));
-    // (waves 4..7 copy one input row each of a sampled batch during the row tail: its index, same way)
-    const bool x_ix = p.row_idx != nullptr && wave >= 4 && row0 + (wave - 4) < p.B;
-    const int x_ld = *(x_ix ? p.row_idx + (row0 + wave - 4) : reinterpret_cast<const int32_t *>(p.slabs));
     // the last weight image (the row tail reads it from LDS): one small load
     const int c4l = m.kr[Lm] >> 2, nl4 = m.kr[Lm - 1] * c4l; // float4s of the last image's logical columns (<= 128 * 4)
     const int wl_r = IS_STATIC ? t / c4l : (int)(((unsigned)t * (((1u << 22) + c4l - 1) / c4l)) >> 22), wl_c = t - wl_r * c4l;
@@ -561,6 +509,18 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     // s_waitcnt vmcnt(0..3) -- AFTER the stores below, which the same counter counts, so the wave sat out a store's round
     // trip to L2 three times (logits, delta_{L-2}, the backward product's start).  Waiting here costs nothing and clears it.
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only (expcnt, lgkmcnt: no wait)
+    // Waves 4..7 copy one input row each of a sampled batch while the row tail runs (below).  Whether a copy is asked for, and
+    // the row's index, are read HERE and by these waves only: the copy's fields sit in a kernel-argument line nothing else has
+    // touched, and the scalar-cache miss that the test costs stood in front of the first vector load when it was made at the
+    // kernel's top (0.3 us whether a copy was asked for or not) and in front of the A_1 barrier when it was made there (0.15).
+    // The index is a SCALAR load (one address per wave; the index vector is not written while this kernel runs).
+    int x_ld = 0;
+    bool x_copy = false;
+    if (wave >= 4) { // (wave-uniform)
+        x_copy = !(TUNE & (1 << 22)) && (p.xcopy || p.xcopyb) && p.row_idx;
+        if (x_copy && row0 + (wave - 4) < p.B)
+            x_ld = *reinterpret_cast<const __attribute__((address_space(4))) int32_t *>(reinterpret_cast<unsigned long long>(p.row_idx + (row0 + wave - 4)));
+    }
     if (wave < 4) {
         if (TUNE & 32) __builtin_amdgcn_s_setprio(3); // the four waves on the critical path, over the image copies of the other four
         const int r = wave, row = row0 + r;
@@ -754,7 +714,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         for (int uu = 0; uu < UPW1; uu++)
             if (!(EARLY_IMG && uu < PF0) && uu < nu_1) to_image_1(uu);
     }
-    if (wave >= 4 && p.row_idx && (p.xcopy || p.xcopyb)) { // (wave-uniform) wave 4 + r: input row r of this block
+    if (wave >= 4 && x_copy) { // (wave-uniform) wave 4 + r: input row r of this block
         // (the row's index was fetched at the top; every load of the row in flight before the first store: as a loop of
         //  load - wait - store the copy took as long as the row tail and held up the barrier behind it)
         const int r = wave - 4, row = row0 + r;
@@ -768,6 +728,8 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                 const int c = 4 * lane + 256 * i;
                 v[i] = *reinterpret_cast<const f32x4 *>(p.X + src + (c < p.ldx ? c : 0));
             }
+            __builtin_amdgcn_s_waitcnt(0x0F70); // (every load of the row waited for HERE: one that a lane does not store stays "pending" for
+                                                //  the compiler, which then drains the memory counter -- the tail's stores included -- behind the barrier)
 #pragma unroll
             for (int i = 0; i < XC; i++) {
                 const int c = 4 * lane + 256 * i;
@@ -780,6 +742,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                 const int c = 4 * lane + 256 * i;
                 v[i] = *reinterpret_cast<const uint2 *>(p.Xb + src + (c < p.ldx ? c : 0));
             }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
             for (int i = 0; i < XC; i++) {
                 const int c = 4 * lane + 256 * i;

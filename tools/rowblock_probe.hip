@@ -118,7 +118,8 @@ int main(int argc, char **argv) {
     time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
     time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, rb); });
     VARIANT(0);   // weights first (2 units), images of waves 4-7 deferred
-    VARIANT(128); // image rows of the first units NOT copied before the A_1 barrier
+    VARIANT(0x400000); // the sampled batch's row copy compiled out
+    VARIANT(0);
     VARIANT(0x100000); // NO weight stream (constants instead of W_1's loads; wrong results): what it costs
     VARIANT(0x200000); // ONE slab load instead of thirteen (wrong results)
     VARIANT(0x300000); // both
