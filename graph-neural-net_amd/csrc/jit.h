@@ -139,8 +139,8 @@ inline const Specialised *get_rowblock(int device, const int *dims, int L, int a
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "gnn_rowblock_jit.hip", 4, hdr_src, hdr_name) != HIPRTC_SUCCESS) { sp.log = "hiprtcCreateProgram failed"; return nullptr; }
     (void)hiprtcAddNameExpression(prog, expr.c_str());
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    const hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-kernarg-preload-count=16"}; // (as build.py: rowblock_kernel.h)
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
     size_t ls = 0;
     if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) { sp.log.assign(ls, '\0'); (void)hiprtcGetProgramLog(prog, &sp.log[0]); }
     std::vector<char> code;

@@ -191,7 +191,9 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
             if (h->dtype == GNN_DTYPE_BF16) { r.Xb = a0_bf16(h, a0); r.xcopyb = h->xstage_b[h->xstage_cur]; }
             else { r.X = a0; r.xcopy = h->xstage[h->xstage_cur]; }
         }
-        void *args[] = {&r};
+        // (the head arguments: rowblock_kernel.h, GNN_RB_HEAD_PARAMS -- in this order)
+        const float *hd_W1 = r.W[1], *hd_Wl = r.W[h->L - 2];
+        void *args[] = {&r.slabs, &hd_W1, &hd_Wl, &r.row_idx, &r.Y, &r.B, &r.slab_rows, &r.ldy, &r};
         const unsigned grid = (unsigned)(pad_up(B) / 4);
         TimerClass &tc = h->timers[GNN_K_MIDDLE];
         hipEvent_t ev0 = nullptr, ev1 = nullptr;

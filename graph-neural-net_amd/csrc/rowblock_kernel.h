@@ -815,9 +815,17 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 }
 
 // TUNE: development knob of tools/rowblock_probe (0 = the shipped schedule)
+// The arguments the kernel's FIRST instructions need travel ahead of the struct (RbHead: 13 dwords): the library is built with
+// -mllvm -amdgpu-kernarg-preload-count=16, so the dispatch hands them over in SGPRs and the first vector loads do not wait
+// for a scalar-cache miss on the kernel-argument segment (6.63 -> 6.45 us, tools/rowblock_probe).  The struct's own copies
+// of these fields are overwritten from them.
+#define GNN_RB_HEAD_PARAMS const float *slabs, const float *W1, const float *Wlast, const int32_t *row_idx, const float *Y, int B, int slab_rows, int ldy
 template <class SH, int ACT, int OUTK, bool STAMP = false, int TUNE = 0, bool BF = false>
-__global__ __launch_bounds__(RB_NT) void rowblock_kernel(RbParams p) {
+__global__ __launch_bounds__(RB_NT) void rowblock_kernel(GNN_RB_HEAD_PARAMS, RbParams p) {
     static_assert(!BF || SH::kL == 3 || SH::kL == 4, "the bf16 row-block kernel: nets of three and four layers");
+    p.slabs = slabs; p.W[1] = W1; p.row_idx = row_idx;
+    if constexpr (SH::kL > 0) p.W[SH::kL - 2] = Wlast; // (the instance for any layer count keeps the struct's own pointer)
+    p.Y = Y; p.B = B; p.slab_rows = slab_rows; p.ldy = ldy;
     if constexpr (SH::is_static) {
         constexpr RbPlan m = SH::make(); // a LOCAL constexpr object: member accesses with constant indices fold to immediates
         static_assert(m.ok, "this shape does not fit the row-block kernel");

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 using namespace gnn;
+#define RBHEAD(r) (r).slabs, (r).W[1], (r).W[2], (r).row_idx, (r).Y, (r).B, (r).slab_rows, (r).ldy // (GNN_RB_HEAD_PARAMS; build with -mllvm -amdgpu-kernarg-preload-count=16)
 using SS = StaticShape<784, 300, 100, 10>;
 using RS = RbStaticShape<784, 300, 100, 10>;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -71,10 +72,10 @@ int main(int argc, char **argv) {
         printf("\n");
     };
     hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4);
-    hipLaunchKernelGGL(k_new, grid, dim3(RB_NT), ldsr, s, rb);
+    hipLaunchKernelGGL(k_new, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb);
     compare("static vs middle4");
     for (int l = 1; l < L; l++) { CK(hipMemset(act[1][l], 0xff, (size_t)Bp * ld[l] * 4)); CK(hipMemset(delta[1][l], 0xff, (size_t)Bp * ld[l] * 4)); }
-    hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, rb);
+    hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb);
     compare("runtime vs middle4");
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto time_it = [&](const char *name, int n, auto fn) {
@@ -88,7 +89,7 @@ int main(int argc, char **argv) {
     auto stamps_of = [&](const char *name, auto kst) {
         CK(hipFuncSetAttribute((const void *)kst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
         CK(hipMemsetAsync(stamps, 0, 4096 * 16 * 8, s));
-        hipLaunchKernelGGL(kst, grid, dim3(RB_NT), ldsr, s, rb);
+        hipLaunchKernelGGL(kst, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb);
         CK(hipStreamSynchronize(s));
         std::vector<unsigned long long> hs((size_t)32 * 16 * 9);
         CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
@@ -110,13 +111,13 @@ int main(int argc, char **argv) {
         auto kv = rowblock_kernel<RS, 0, 0, false, T>; \
         CK(hipFuncSetAttribute((const void *)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr)); \
         for (int l = 1; l < L; l++) { CK(hipMemset(act[1][l], 0xff, (size_t)Bp * ld[l] * 4)); CK(hipMemset(delta[1][l], 0xff, (size_t)Bp * ld[l] * 4)); } \
-        hipLaunchKernelGGL(kv, grid, dim3(RB_NT), ldsr, s, rb); \
+        hipLaunchKernelGGL(kv, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb); \
         compare("TUNE=" #T " vs middle4"); \
-        time_it("rowblock<static> TUNE=" #T, 500, [&]() { hipLaunchKernelGGL(kv, grid, dim3(RB_NT), ldsr, s, rb); }); \
+        time_it("rowblock<static> TUNE=" #T, 500, [&]() { hipLaunchKernelGGL(kv, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb); }); \
         stamps_of("TUNE=" #T, rowblock_kernel<RS, 0, 0, true, T>); \
     } while (0)
     time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
-    time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, rb); });
+    time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb); });
     VARIANT(0);   // weights first (2 units), images of waves 4-7 deferred
     VARIANT(0x400000); // the sampled batch's row copy compiled out
     VARIANT(0);
