@@ -1,11 +1,7 @@
 // launch_misc.hip -- host side of the element-wise kernels (kernels.h): input / label encodings (MT:92-118), row
 // gathers (NNT:143-158), exports, and the flat momentum update after an all-reduce (SCE:327-342).
 #include "handle.h"
-
-#include <atomic>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
+#include "convert_helper.h"
 
 using namespace gnn;
 using namespace gnn::host;
@@ -31,76 +27,6 @@ void launch_onehot_u8(gnn_mlp *h, const uint8_t *lab, int n_classes, float *dst,
 // GPU's cvt applies), the staging kernel reads the slot across PCIe, and the call returns: the NEXT call's conversion
 // runs while this step's kernels do.  No host pointer outlives the call.
 namespace {
-void rows_to_f32_plain(const double *src, float *dst, size_t n) {
-    for (size_t i = 0; i < n; i++) dst[i] = (float)src[i];
-}
-__attribute__((target("avx2"))) void rows_to_f32_avx2(const double *src, float *dst, size_t n) {
-    for (size_t i = 0; i < n; i++) dst[i] = (float)src[i]; // (vectorised by the compiler: vcvtpd2ps)
-}
-void rows_to_f32(const double *src, float *dst, size_t n) {
-    static const bool avx2 = __builtin_cpu_supports("avx2");
-    if (avx2) rows_to_f32_avx2(src, dst, n);
-    else rows_to_f32_plain(src, dst, n);
-}
-
-// The conversion is the call's largest host cost (0.8 MB read, 0.4 MB written per 128-row batch of 784 inputs: ~20 us on
-// one core).  ONE helper thread per process takes the second half of a large batch while the calling thread does the first;
-// it sleeps on a condition variable between calls (no spinning while the caller is elsewhere).  If the thread cannot be
-// created the caller converts everything itself.
-class ConvertHelper {
-  public:
-    ~ConvertHelper() {
-        { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
-        cv_.notify_all();
-        if (th_.joinable()) th_.join();
-    }
-    // converts [src, src + n) into dst using the helper for the upper part; returns when ALL of it is done
-    void run(const double *src, float *dst, size_t n) {
-        std::unique_lock<std::mutex> call(call_mu_, std::try_to_lock); // one batch at a time; a second caller converts alone
-        if (n < (size_t)1 << 15 || !call.owns_lock() || !start()) { rows_to_f32(src, dst, n); return; }
-        const size_t mine = (n * 9 / 16) & ~(size_t)15; // a little more than half: the helper has to wake up first
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            src_ = src + mine; dst_ = dst + mine; n_ = n - mine;
-            done_.store(false, std::memory_order_relaxed);
-            pending_ = true;
-        }
-        cv_.notify_one();
-        rows_to_f32(src, dst, mine);
-        while (!done_.load(std::memory_order_acquire)) __builtin_ia32_pause(); // (microseconds: the helper started long ago)
-    }
-
-  private:
-    bool start() {
-        if (started_) return ok_;
-        started_ = true;
-        try {
-            th_ = std::thread([this]() {
-                std::unique_lock<std::mutex> lk(mu_);
-                for (;;) {
-                    cv_.wait(lk, [this] { return pending_ || quit_; });
-                    if (quit_) return;
-                    pending_ = false;
-                    const double *s = src_; float *d = dst_; const size_t n = n_;
-                    lk.unlock();
-                    rows_to_f32(s, d, n);
-                    done_.store(true, std::memory_order_release);
-                    lk.lock();
-                }
-            });
-            ok_ = true;
-        } catch (...) {
-            ok_ = false;
-        }
-        return ok_;
-    }
-    std::mutex mu_, call_mu_;
-    std::condition_variable cv_;
-    std::thread th_;
-    bool started_ = false, ok_ = false, pending_ = false, quit_ = false;
-    const double *src_ = nullptr; float *dst_ = nullptr; size_t n_ = 0;
-    std::atomic<bool> done_{true};
-};
 ConvertHelper g_convert;
 } // namespace
 
