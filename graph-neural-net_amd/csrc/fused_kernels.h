@@ -328,8 +328,8 @@ __global__ __launch_bounds__(NTHR) void grad_update_kernel(GradParams p) {
 // 8 waves = 2x2 sub-tiles of 32x32 (2x2 MFMA tiles each, rows/columns interleaved so that an operand
 // fragment is one ds_read_b64) x 2 halves of every 64-row K chunk; partial tiles meet in LDS.
 // ------------------------------------------------------------------------------------------
-template <bool FUSED>
-__global__ __launch_bounds__(512) void grad_update64_kernel(GradParams p) {
+template <bool FUSED, bool PF = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void grad_update64_kernel(GradParams p) {
     constexpr int T = 64, KC = 64, LD = T + 16, CLD = T + 4;
     __shared__ __attribute__((aligned(16))) float sm[2 * KC * LD]; // A and D panels; later the two partial tiles
     static_assert(2 * T * CLD <= 2 * KC * LD, "partial tiles reuse the operand panels");
@@ -356,7 +356,17 @@ __global__ __launch_bounds__(512) void grad_update64_kernel(GradParams p) {
         e_ok[i] = (m0 + er + 32 * i < L.M) && (n0 + eq * 4 < L.N);
         e_off[i] = (size_t)(m0 + er + 32 * i) * L.ldd + n0 + eq * 4;
         w_old[i] = make_float4(0.f, 0.f, 0.f, 0.f); v_old[i] = w_old[i];
-        if (FUSED && e_ok[i]) { // W / V rows first: their latency hides under the GEMM
+    }
+    // tiles wholly inside their layer with the batch rows in place load without bounds tests (see gemm_f32_kernel)
+    const bool interior = (m0 + T <= L.M) && (n0 + T <= L.N) && (p.K % KC == 0) && !(li == 0 && p.row_idx) &&
+                          (unsigned long long)p.K * (unsigned)(L.lda > L.ldd ? L.lda : L.ldd) < 0xffffffffull; // 32-bit offsets
+    // PF, interior tiles: the NEXT chunk's operands are requested before this chunk's MFMAs and the W / V rows take those
+    // registers' place during the last chunk -- held from the start they cost the 16 VGPRs the prefetch needs (3 -> 2
+    // workgroups per CU with both)
+    const bool late_wv = PF && interior;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (FUSED && e_ok[i] && !late_wv) { // W / V rows first: their latency hides under the GEMM
             w_old[i] = *reinterpret_cast<const float4 *>(L.W + e_off[i]);
             v_old[i] = *reinterpret_cast<const float4 *>(L.V + e_off[i]);
         }
@@ -368,9 +378,68 @@ __global__ __launch_bounds__(512) void grad_update64_kernel(GradParams p) {
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // tiles wholly inside their layer with the batch rows in place load without bounds tests (see gemm_f32_kernel)
-    const bool interior = (m0 + T <= L.M) && (n0 + T <= L.N) && (p.K % KC == 0) && !(li == 0 && p.row_idx) &&
-                          (unsigned long long)p.K * (unsigned)(L.lda > L.ldd ? L.lda : L.ldd) < 0xffffffffull; // 32-bit offsets
+    if (late_wv) {
+        // (named registers and macros, not arrays captured by lambdas: those were given a home in scratch memory)
+        float4 va0, va1, vd0, vd1;
+        const unsigned rk = (unsigned)(t >> 4), rq = (unsigned)(t & 15) * 4;
+#define GNN_GU64_REQUEST(k0_)                                                                                                   \
+    do {                                                                                                                        \
+        va0 = *reinterpret_cast<const float4 *>(L.A + (((unsigned)(k0_) + rk) * (unsigned)L.lda + m0 + rq));                    \
+        va1 = *reinterpret_cast<const float4 *>(L.A + (((unsigned)(k0_) + rk + 32) * (unsigned)L.lda + m0 + rq));               \
+        vd0 = *reinterpret_cast<const float4 *>(L.D + (((unsigned)(k0_) + rk) * (unsigned)L.ldd + n0 + rq));                    \
+        vd1 = *reinterpret_cast<const float4 *>(L.D + (((unsigned)(k0_) + rk + 32) * (unsigned)L.ldd + n0 + rq));               \
+    } while (0)
+#define GNN_GU64_LAND()                                                                                                         \
+    do {                                                                                                                        \
+        *reinterpret_cast<float4 *>(&As[rk * LD + rq]) = va0;                                                                   \
+        *reinterpret_cast<float4 *>(&As[(rk + 32) * LD + rq]) = va1;                                                            \
+        *reinterpret_cast<float4 *>(&Ds[rk * LD + rq]) = vd0;                                                                   \
+        *reinterpret_cast<float4 *>(&Ds[(rk + 32) * LD + rq]) = vd1;                                                            \
+    } while (0)
+        GNN_GU64_REQUEST(0);
+        const float *ap = &As[(kh * (KC / 2) + fq) * LD + wm * 32 + fr * 2];
+        const float *dp = &Ds[(kh * (KC / 2) + fq) * LD + wn * 32 + fr * 2];
+        auto multiply = [&]() { // this wave's half of the chunk
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; kk += 16) {
+                f32x2 a[4], d[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    a[u] = *reinterpret_cast<const f32x2 *>(ap + (kk + 4 * u) * LD);
+                    d[u] = *reinterpret_cast<const f32x2 *>(dp + (kk + 4 * u) * LD);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], d[u][j], acc[i][j], 0, 0, 0);
+            }
+        };
+        int k0 = 0;
+        for (; k0 + KC < p.K; k0 += KC) {
+            if (k0) __syncthreads();
+            GNN_GU64_LAND();
+            __syncthreads();
+            GNN_GU64_REQUEST(k0 + KC);
+            __builtin_amdgcn_sched_barrier(0); // (the scheduler otherwise sinks the requests behind the MFMAs, next to their use)
+            multiply();
+        }
+        if (k0) __syncthreads();
+        GNN_GU64_LAND();
+        __syncthreads();
+#undef GNN_GU64_REQUEST
+#undef GNN_GU64_LAND
+        if (FUSED) { // (the last chunk: the W / V rows ride where the operand prefetch did)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                w_old[i] = *reinterpret_cast<const float4 *>(L.W + e_off[i]);
+                v_old[i] = *reinterpret_cast<const float4 *>(L.V + e_off[i]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        multiply();
+    } else
     for (int k0 = 0; k0 < p.K; k0 += KC) {
         const int kc = (p.K - k0 < KC) ? p.K - k0 : KC; // a multiple of 16
         if (k0) __syncthreads();

@@ -262,14 +262,17 @@ void to_bf16(gnn_mlp *h, const float *src, __bf16 *dst, size_t n);
 
 // ---- launch_small.hip: the row-block kernel and the tile-owner kernel ----------------------------
 struct NextBatch { const float *a0; const int32_t *idx; int B; };
+// which rows the row-block kernel copies to a staging buffer while its row tail runs (RbParams::xcopy): none, its own
+// sampled batch's (to xstage[xstage_cur]), or the announced NEXT sampled batch's (to the other buffer)
+enum { RB_COPY_NONE = 0, RB_COPY_CURRENT = 1, RB_COPY_NEXT = 2 };
 struct PeerGradients { const float *G[TS_MAX_PEERS]; int n; unsigned slice; }; // gsrc 3 / 4 of launch_tile_step (dp.hip)
 void plan_mid4(gnn_mlp *h);
 void plan_rowblock(gnn_mlp *h); // (after plan_chain: the kernel exists for the two-launch step only)
 void try_specialize(gnn_mlp *h);
 void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
-                   bool want_loss, bool want_label, bool from_slabs = false, bool copy_rows = false);
+                   bool want_loss, bool want_label, bool from_slabs = false, int copy_rows = RB_COPY_NONE);
 void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, const float *a0, int B, float step_over_b, float momentum,
-                      bool staged = false, const PeerGradients *peers = nullptr);
+                      bool staged = false, const PeerGradients *peers = nullptr, bool next_staged = false);
 
 // ---- launch_misc.hip: encodings, gathers, the flat update ---------------------------------------
 void launch_convert_rows(gnn_mlp *h, const double *src, int d, float *dst, int ld, int64_t rows, int64_t rows_pad, int act, int apply_act);
@@ -287,7 +290,7 @@ void plan_chain(gnn_mlp *h);
 const __bf16 *a0_bf16(const gnn_mlp *h, const float *a0);
 bool slabs_hold(const gnn_mlp *h, const float *a0, const int32_t *idx, int B);
 bool take_next(gnn_mlp *h, NextBatch *nb);
-void slabs_now_hold(gnn_mlp *h, const NextBatch &nb, bool staged_copy = false);
+void slabs_now_hold(gnn_mlp *h, const NextBatch &nb, bool staged_copy = false, bool by_rowblock = false);
 void hint_range(gnn_mlp *h, int64_t row0, int B);
 void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_prob, bool want_loss, bool want_label);
 void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum,

@@ -198,7 +198,9 @@ void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float
     g.row_idx = h->cur_idx; g.k_true = B;
     g.step_over_b = step_over_b; g.momentum = momentum;
     if (big) {
-        if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update64_kernel<true>, dim3(h->grad_tiles64), dim3(512), 0, g);
+        // <true, true>: interior tiles request the next chunk's operands ahead of this chunk's MFMAs (784-1024^3-10 at 256 rows: 78.3 -> 76.8 us
+        // per step in one run, profiles/r03/config5_gradient_prefetch.log)
+        if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update64_kernel<true, true>, dim3(h->grad_tiles64), dim3(512), 0, g);
         else launch_timed(h, GNN_K_GRAD_GEMM0, grad_update64_kernel<false>, dim3(h->grad_tiles64), dim3(512), 0, g);
     } else {
         if (fused_update) launch_timed(h, GNN_K_GRAD_GEMM0, grad_update_kernel<true>, dim3(h->grad_tiles), dim3(GRAD_THREADS), 0, g);

@@ -175,7 +175,7 @@ void try_specialize(gnn_mlp *h) {
 // forward of the middle4 path; backward = also delta_1..delta_{L-1}
 // from_slabs: A_1 = f(sum of the K slabs) (tile_step_kernel made them); else fwd_first_kernel writes act[1] first
 void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob,
-                   bool want_loss, bool want_label, bool from_slabs, bool copy_rows) {
+                   bool want_loss, bool want_label, bool from_slabs, int copy_rows) {
     if (!from_slabs) launch_fwd_first(h, a0, B);
     if (from_slabs && h->rb) { // the two-launch step's training kernel (rowblock_kernel.h)
         RbParams r = h->rbp;
@@ -186,10 +186,14 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
         r.label = want_label ? h->labels : nullptr;
         r.B = B;
         r.row_idx = h->cur_idx;
-        if (copy_rows && h->cur_idx) { // the sampled batch's rows, contiguous, for the tile kernel that follows (RbParams::xcopy)
-            r.ldx = h->ld[0];
+        if (copy_rows == RB_COPY_CURRENT && h->cur_idx) { // the sampled batch's rows, contiguous, for the tile kernel that follows (RbParams::xcopy)
+            r.ldx = h->ld[0]; r.copy_idx = h->cur_idx; r.copy_B = B;
             if (h->dtype == GNN_DTYPE_BF16) { r.Xb = a0_bf16(h, a0); r.xcopyb = h->xstage_b[h->xstage_cur]; }
             else { r.X = a0; r.xcopy = h->xstage[h->xstage_cur]; }
+        } else if (copy_rows == RB_COPY_NEXT && h->have_next && h->next_idx) { // the announced next batch's rows, to the OTHER buffer
+            r.ldx = h->ld[0]; r.copy_idx = h->next_idx; r.copy_B = h->next_B;
+            if (h->dtype == GNN_DTYPE_BF16) { r.Xb = a0_bf16(h, h->next_a0); r.xcopyb = h->xstage_b[h->xstage_cur ^ 1]; }
+            else { r.X = h->next_a0; r.xcopy = h->xstage[h->xstage_cur ^ 1]; }
         }
         // (the head arguments: rowblock_kernel.h, GNN_RB_HEAD_PARAMS -- in this order)
         const float *hd_W1 = r.W[1], *hd_Wl = r.W[h->L - 2];
@@ -252,7 +256,7 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
 // gsrc / gdst / fwd as in tile_step_kernel.h; fwd_only_layer0: the grid covers layer 0's tiles only
 // staged: the current batch's rows come from the contiguous copy xstage[xstage_cur] instead of (a0, cur_idx)
 void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, const float *a0, int B, float step_over_b, float momentum,
-                      bool staged, const PeerGradients *peers) {
+                      bool staged, const PeerGradients *peers, bool next_staged) {
     TileStepParams t = h->tsp;
     if (peers) {
         for (int r = 0; r < peers->n; r++) t.Gpeer[r] = peers->G[r];
@@ -267,6 +271,7 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
     t.step_over_b = step_over_b; t.momentum = momentum;
     const bool fwd = next != nullptr;
     if (fwd) { t.An = next->a0; t.ldan = h->ld[0]; t.next_idx = next->idx; t.next_rows = next->B; t.next_K = pad_up(next->B); }
+    if (fwd && next_staged) { t.An = h->xstage[stage_dst]; t.next_idx = nullptr; } // (the row-block kernel in front of this launch copied the rows)
     const bool fwd_only = gsrc == 0;
     const dim3 grid(fwd_only ? h->ts_tiles0 : h->ts_tiles), block(TS_THREADS);
     if (fwd_only) t.n_layers = 1;
@@ -277,7 +282,7 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
     if (h->dtype == GNN_DTYPE_BF16) {
         if (staged) t.Ab[0] = h->xstage_b[h->xstage_cur];
         else if (a0) t.Ab[0] = a0_bf16(h, a0);
-        if (fwd) t.Anb = a0_bf16(h, next->a0);
+        if (fwd) t.Anb = next_staged ? h->xstage_b[stage_dst] : a0_bf16(h, next->a0);
         if (fwd_only) launch_timed(h, cls, tile_step_bf16_kernel<0, 0, true>, grid, block, 0, t);
         else if (gsrc == 1 && gdst == 1) launch_timed(h, cls, tile_step_bf16_kernel<1, 1, false>, grid, block, 0, t);
         else if (gsrc == 1 && gdst == 2 && !fwd) launch_timed(h, cls, tile_step_bf16_kernel<1, 2, false>, grid, block, 0, t);

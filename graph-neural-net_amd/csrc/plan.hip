@@ -154,8 +154,8 @@ bool take_next(gnn_mlp *h, NextBatch *nb) {
     return true;
 }
 // staged_copy: the launch that made these slabs also wrote the batch's rows to the other staging buffer
-void slabs_now_hold(gnn_mlp *h, const NextBatch &nb, bool staged_copy) {
-    if (h->rb) staged_copy = false; // (on the row-block kernel's path the tile kernel writes no copy: that kernel does, for its own batch)
+void slabs_now_hold(gnn_mlp *h, const NextBatch &nb, bool staged_copy, bool by_rowblock) {
+    if (h->rb && !by_rowblock) staged_copy = false; // (on the row-block kernel's path the tile kernel writes no copy: that kernel does)
     h->slab_valid = true; h->slab_a0 = nb.a0; h->slab_idx = nb.idx; h->slab_B = nb.B;
     if (staged_copy) h->xstage_cur ^= 1;
     h->xstage_valid = staged_copy;
@@ -169,15 +169,22 @@ void chain_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fus
         launch_tile_step(h, 0, 0, &self, a0, B, 0.f, 0.f); // chain start: the slabs of this batch from the weights as they are
         slabs_now_hold(h, self, self.idx != nullptr);
     }
-    const bool rb_copy = h->rb && h->cur_idx != nullptr; // a sampled batch on the row-block kernel's path: that kernel leaves the contiguous copy
-    const bool staged = rb_copy || (h->xstage_valid && h->cur_idx != nullptr); // (else: the tile launch that made the slabs did)
+    // A sampled batch on the row-block kernel's path: that kernel makes the contiguous copies the tile kernel reads with plain
+    // addressing.  In a training loop that announces its next batch (train_sampled) it copies the NEXT batch's rows: the tile
+    // kernel's first-layer product reads them without an index -> address -> row chain at its top (7.25 -> 5.6 us per launch at
+    // 784-300-100-10), and one step later the same copy is the gradient operand.  Without an announced sampled batch of the same
+    // size it copies its own rows, for the gradient product only (the first step of a chain gathers that operand by index).
+    const bool have_copy = h->xstage_valid && h->cur_idx != nullptr; // (made one step ago, or by the tile launch that made the slabs)
+    const bool rb_next = h->rb && fused_update && h->have_next && h->next_idx != nullptr && h->next_B == B;
+    const bool rb_cur = h->rb && !rb_next && !have_copy && h->cur_idx != nullptr;
+    const bool staged = have_copy || rb_cur;
     h->slab_valid = false;
-    fused_forward(h, a0, y, B, true, false, false, false, true, rb_copy);
+    fused_forward(h, a0, y, B, true, false, false, false, true, rb_next ? RB_COPY_NEXT : rb_cur ? RB_COPY_CURRENT : RB_COPY_NONE);
     NextBatch nb{};
     if (fused_update) {
         const bool fwd = take_next(h, &nb);
-        launch_tile_step(h, 1, 2, fwd ? &nb : nullptr, a0, B, step_over_b, momentum, staged);
-        if (fwd) slabs_now_hold(h, nb, nb.idx != nullptr);
+        launch_tile_step(h, 1, 2, fwd ? &nb : nullptr, a0, B, step_over_b, momentum, staged, nullptr, rb_next);
+        if (fwd) slabs_now_hold(h, nb, rb_next || nb.idx != nullptr, rb_next);
         else h->xstage_valid = false;
     } else {
         launch_tile_step(h, 1, 1, nullptr, a0, B, 0.f, 0.f, staged);

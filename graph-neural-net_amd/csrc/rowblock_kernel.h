@@ -124,7 +124,11 @@ struct RbParams {
     // its gradient operand A_0 from the copy with plain addressing (the same copy written by the PREVIOUS tile kernel cost it
     // 0.8 us: tools/tile_probe).  Null = no copy.  (Beside row_idx and slabs: the kernel's top reads these fields, and a field
     // in a kernel-argument cache line of its own is one more scalar-cache miss in front of the first load.)
+    // Which rows: copy_idx[r] for r < copy_B (zeros behind them) -- this batch's own rows (copy_idx == row_idx), or the NEXT batch's
+    // when the caller has announced it: the tile kernel that follows then reads the next batch's rows for its first-layer
+    // product with plain addressing too, and the copy is this batch's gradient operand one step later (plan.hip, chain_gradient).
     float *xcopy; __bf16 *xcopyb; const float *X; const __bf16 *Xb; int ldx;
+    const int32_t *copy_idx; int copy_B;
     unsigned long long *stamps;  // STAMP builds only: 16 slots per workgroup
     // bf16 kernels (BF): the bf16 shadow of W_l and the bf16 outputs the tile kernel reads, as in Mid4Params
     const __bf16 *Wb[MAX_LAYERS];
@@ -517,9 +521,9 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     int x_ld = 0;
     bool x_copy = false;
     if (wave >= 4) { // (wave-uniform)
-        x_copy = !(TUNE & (1 << 22)) && (p.xcopy || p.xcopyb) && p.row_idx;
-        if (x_copy && row0 + (wave - 4) < p.B)
-            x_ld = *reinterpret_cast<const __attribute__((address_space(4))) int32_t *>(reinterpret_cast<unsigned long long>(p.row_idx + (row0 + wave - 4)));
+        x_copy = !(TUNE & (1 << 22)) && (p.xcopy || p.xcopyb) && p.copy_idx;
+        if (x_copy && row0 + (wave - 4) < p.copy_B)
+            x_ld = *reinterpret_cast<const __attribute__((address_space(4))) int32_t *>(reinterpret_cast<unsigned long long>(p.copy_idx + (row0 + wave - 4)));
     }
     if (wave < 4) {
         if (TUNE & 32) __builtin_amdgcn_s_setprio(3); // the four waves on the critical path, over the image copies of the other four
@@ -718,7 +722,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         // (the row's index was fetched at the top; every load of the row in flight before the first store: as a loop of
         //  load - wait - store the copy took as long as the row tail and held up the barrier behind it)
         const int r = wave - 4, row = row0 + r;
-        const bool live = row < p.B;
+        const bool live = row < p.copy_B;
         const size_t src = live ? (size_t)x_ld * p.ldx : 0, dst = (size_t)row * p.ldx;
         constexpr int XC = 4; // 4 x 64 lanes x 4 elements = 1024 columns
         if (p.xcopy) {

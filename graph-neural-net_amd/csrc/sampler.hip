@@ -11,28 +11,54 @@
 using namespace gnn;
 using namespace gnn::host;
 
+// The k-th set bit (k 0-based, k < popcount) of a 64-bit word: deposit one bit at the k-th set position, count the zeros below it.
+__attribute__((target("bmi2"))) static inline int select_bit_bmi2(uint64_t w, int k) { return (int)__builtin_ctzll(__builtin_ia32_pdep_di(1ull << k, w)); }
+static inline int select_bit_plain(uint64_t w, int k) {
+    for (; k > 0; k--) w &= w - 1;
+    return (int)__builtin_ctzll(w);
+}
+
 struct gnn_sampler {
     int32_t master = 0, remaining = 0;
-    std::vector<int32_t> fen; // Fenwick tree over "row still in dataSampler": the r-th remaining
-                              // row in master order is what ArrayList.get(r) returns after removals
+    // "row still in dataSampler" as one bit per row, 64 rows per word, and a Fenwick tree over the words' counts: the r-th
+    // remaining row in master order is what ArrayList.get(r) returns after removals (NNT:152-154).  A tree over words, not
+    // rows: 938 counters for MNIST's 60 000 rows stay in L1 and the walk is 10 levels instead of 16 through L2 -- the sampler
+    // feeds a training loop whose step is 13 us, and at two row-level walks per draw it was the slower of the two
+    // (14.3 us per batch of 128 against 13.2; tools/bench_trainer.py).
+    std::vector<uint64_t> bits;
+    std::vector<int32_t> fen; // 1-based over the words
+    int32_t words = 0;
     JavaRandom rnd{1};
-    int log2n = 0;
+    int log2w = 0;
+    bool bmi2 = false;
     void refill() { // refillSampler NNT:164-168
-        fen.assign((size_t)master + 1, 0);
-        for (int32_t i = 1; i <= master; i++) {
-            fen[i] += 1;
+        bits.assign((size_t)words, ~0ull);
+        if (master % 64) bits[(size_t)words - 1] = (1ull << (master % 64)) - 1;
+        // (entries behind the last word, up to the next power of two, read as "more than any k": the walk below needs no bounds test)
+        fen.assign(((size_t)2 << log2w) + 1, INT32_MAX);
+        std::fill(fen.begin(), fen.begin() + words + 1, 0);
+        for (int32_t i = 1; i <= words; i++) {
+            fen[i] += (int32_t)__builtin_popcountll(bits[(size_t)i - 1]);
             const int32_t j = i + (i & -i);
-            if (j <= master) fen[j] += fen[i];
+            if (j <= words) fen[j] += fen[i];
         }
         remaining = master;
     }
     int32_t take(int32_t r) { // remove and return the r-th (0-based) remaining row
         int32_t pos = 0, k = r + 1;
-        for (int32_t pw = 1 << log2n; pw > 0; pw >>= 1)
-            if (pos + pw <= master && fen[pos + pw] < k) { pos += pw; k -= fen[pos]; }
-        for (int32_t i = pos + 1; i <= master; i += i & -i) fen[i] -= 1;
+        for (int32_t pw = 1 << log2w; pw > 0; pw >>= 1) { // (selects, not branches: the comparison is a coin toss per level)
+            const int32_t f = fen[pos + pw];
+            const bool go = f < k;
+            pos += go ? pw : 0;
+            k -= go ? f : 0;
+        }
+        // word `pos` (0-based) holds the row: its (k-1)-th set bit
+        const uint64_t w = bits[(size_t)pos];
+        const int bit = bmi2 ? select_bit_bmi2(w, k - 1) : select_bit_plain(w, k - 1);
+        bits[(size_t)pos] = w & ~(1ull << bit);
+        for (int32_t i = pos + 1; i <= words; i += i & -i) fen[i] -= 1;
         remaining--;
-        return pos; // 0-based row
+        return pos * 64 + bit; // 0-based row
     }
 };
 
@@ -42,8 +68,10 @@ int gnn_sampler_create(int32_t master_size, int64_t seed, gnn_sampler_t **out) {
     if (!out || master_size <= 0) return fail(GNN_ERR_BAD_ARG, "bad sampler arguments");
     gnn_sampler *s = new gnn_sampler();
     s->master = master_size;
+    s->words = (master_size + 63) / 64;
     s->rnd.set_seed(seed);
-    while ((1 << (s->log2n + 1)) <= master_size) s->log2n++;
+    while ((1 << (s->log2w + 1)) <= s->words) s->log2w++;
+    s->bmi2 = __builtin_cpu_supports("bmi2");
     s->refill();
     *out = s;
     return GNN_OK;
@@ -53,13 +81,13 @@ int gnn_sampler_destroy(gnn_sampler_t *s) { delete s; return GNN_OK; }
 
 int gnn_sampler_sample(gnn_sampler_t *s, int batch, int32_t *out_idx, int *n_out) { return guarded([&]() -> int {
     if (!s || !out_idx || !n_out || batch <= 0) return fail(GNN_ERR_BAD_ARG, "bad sampler arguments");
-    int n = 0;
+    int n = 0, before_refill = 0; // rows drawn before a refill inside this batch: only THEY can come again (within an epoch rows are distinct)
     for (int i = 0; i < batch; i++) {
-        if (s->remaining == 0) s->refill();                       // NNT:149-151
+        if (s->remaining == 0) { s->refill(); before_refill = n; } // NNT:149-151
         const int32_t r = s->rnd.next_int(s->remaining);           // NNT:152
         const int32_t row = s->take(r);                            // NNT:153-154
         bool dup = false;                                          // HashMap.put, NNT:155
-        for (int k = 0; k < n; k++) if (out_idx[k] == row) { dup = true; break; }
+        for (int k = 0; k < before_refill; k++) if (out_idx[k] == row) { dup = true; break; }
         if (!dup) out_idx[n++] = row;
     }
     *n_out = n;
