@@ -187,17 +187,17 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
         r.B = B;
         r.row_idx = h->cur_idx;
         if (copy_rows == RB_COPY_CURRENT && h->cur_idx) { // the sampled batch's rows, contiguous, for the tile kernel that follows (RbParams::xcopy)
-            r.ldx = h->ld[0]; r.copy_idx = h->cur_idx; r.copy_B = B;
+            r.ldx = h->ld[0]; r.copy_idx = h->cur_idx;
             if (h->dtype == GNN_DTYPE_BF16) { r.Xb = a0_bf16(h, a0); r.xcopyb = h->xstage_b[h->xstage_cur]; }
             else { r.X = a0; r.xcopy = h->xstage[h->xstage_cur]; }
         } else if (copy_rows == RB_COPY_NEXT && h->have_next && h->next_idx) { // the announced next batch's rows, to the OTHER buffer
-            r.ldx = h->ld[0]; r.copy_idx = h->next_idx; r.copy_B = h->next_B;
+            r.ldx = h->ld[0]; r.copy_idx = h->next_idx; // (next_B == B: chain_gradient)
             if (h->dtype == GNN_DTYPE_BF16) { r.Xb = a0_bf16(h, h->next_a0); r.xcopyb = h->xstage_b[h->xstage_cur ^ 1]; }
             else { r.X = h->next_a0; r.xcopy = h->xstage[h->xstage_cur ^ 1]; }
         }
         // (the head arguments: rowblock_kernel.h, GNN_RB_HEAD_PARAMS -- in this order)
         const float *hd_W1 = r.W[1], *hd_Wl = r.W[h->L - 2];
-        void *args[] = {&r.slabs, &hd_W1, &hd_Wl, &r.row_idx, &r.Y, &r.B, &r.slab_rows, &r.ldy, &r};
+        void *args[] = {&r.slabs, &hd_W1, &hd_Wl, &r.row_idx, &r.Y, &r.copy_idx, &r.B, &r.slab_rows, &r.ldy, &r};
         const unsigned grid = (unsigned)(pad_up(B) / 4);
         TimerClass &tc = h->timers[GNN_K_MIDDLE];
         hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -124,11 +124,11 @@ struct RbParams {
     // its gradient operand A_0 from the copy with plain addressing (the same copy written by the PREVIOUS tile kernel cost it
     // 0.8 us: tools/tile_probe).  Null = no copy.  (Beside row_idx and slabs: the kernel's top reads these fields, and a field
     // in a kernel-argument cache line of its own is one more scalar-cache miss in front of the first load.)
-    // Which rows: copy_idx[r] for r < copy_B (zeros behind them) -- this batch's own rows (copy_idx == row_idx), or the NEXT batch's
+    // Which rows: copy_idx[r] for r < B (zeros behind them) -- this batch's own rows (copy_idx == row_idx), or the NEXT batch's
     // when the caller has announced it: the tile kernel that follows then reads the next batch's rows for its first-layer
     // product with plain addressing too, and the copy is this batch's gradient operand one step later (plan.hip, chain_gradient).
     float *xcopy; __bf16 *xcopyb; const float *X; const __bf16 *Xb; int ldx;
-    const int32_t *copy_idx; int copy_B;
+    const int32_t *copy_idx;
     unsigned long long *stamps;  // STAMP builds only: 16 slots per workgroup
     // bf16 kernels (BF): the bf16 shadow of W_l and the bf16 outputs the tile kernel reads, as in Mid4Params
     const __bf16 *Wb[MAX_LAYERS];
@@ -200,6 +200,9 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int row0 = blockIdx.x * 4;
+    int x_ld_top = 0; // waves 4..7: the data-set row this wave copies during the row tail (below), a scalar load
+    if (wave >= 4 && p.copy_idx && row0 + (wave - 4) < p.B)
+        x_ld_top = *reinterpret_cast<const __attribute__((address_space(4))) int32_t *>(reinterpret_cast<unsigned long long>(p.copy_idx + (row0 + wave - 4)));
     const int L = (NL > 0) ? NL : m.L, Lm = L - 1;
     // BF (GNN_DTYPE_BF16, nets of three and four layers): every operand of the products carries a bf16 value -- weights from
     // the bf16 shadow (half the bytes of the kernel's dominant load), activations and deltas rounded as they enter their
@@ -518,13 +521,11 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     // touched, and the scalar-cache miss that the test costs stood in front of the first vector load when it was made at the
     // kernel's top (0.3 us whether a copy was asked for or not) and in front of the A_1 barrier when it was made there (0.15).
     // The index is a SCALAR load (one address per wave; the index vector is not written while this kernel runs).
-    int x_ld = 0;
+    // (The row's index: requested at the kernel's top, x_ld_top -- copy_idx and B arrive in SGPRs with the dispatch, so that
+    //  test costs no miss; the NEXT batch's indices and rows are cold in L2, and index -> row behind each other did not fit under the row tail.)
+    const int x_ld = x_ld_top;
     bool x_copy = false;
-    if (wave >= 4) { // (wave-uniform)
-        x_copy = !(TUNE & (1 << 22)) && (p.xcopy || p.xcopyb) && p.copy_idx;
-        if (x_copy && row0 + (wave - 4) < p.copy_B)
-            x_ld = *reinterpret_cast<const __attribute__((address_space(4))) int32_t *>(reinterpret_cast<unsigned long long>(p.copy_idx + (row0 + wave - 4)));
-    }
+    if (wave >= 4) x_copy = !(TUNE & (1 << 22)) && (p.xcopy || p.xcopyb) && p.copy_idx; // (wave-uniform)
     if (wave < 4) {
         if (TUNE & 32) __builtin_amdgcn_s_setprio(3); // the four waves on the critical path, over the image copies of the other four
         const int r = wave, row = row0 + r;
@@ -722,7 +723,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         // (the row's index was fetched at the top; every load of the row in flight before the first store: as a loop of
         //  load - wait - store the copy took as long as the row tail and held up the barrier behind it)
         const int r = wave - 4, row = row0 + r;
-        const bool live = row < p.copy_B;
+        const bool live = row < p.B; // (a copied batch has this batch's row count: chain_gradient)
         const size_t src = live ? (size_t)x_ld * p.ldx : 0, dst = (size_t)row * p.ldx;
         constexpr int XC = 4; // 4 x 64 lanes x 4 elements = 1024 columns
         if (p.xcopy) {
@@ -823,11 +824,11 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 // -mllvm -amdgpu-kernarg-preload-count=16, so the dispatch hands them over in SGPRs and the first vector loads do not wait
 // for a scalar-cache miss on the kernel-argument segment (6.63 -> 6.45 us, tools/rowblock_probe).  The struct's own copies
 // of these fields are overwritten from them.
-#define GNN_RB_HEAD_PARAMS const float *slabs, const float *W1, const float *Wlast, const int32_t *row_idx, const float *Y, int B, int slab_rows, int ldy
+#define GNN_RB_HEAD_PARAMS const float *slabs, const float *W1, const float *Wlast, const int32_t *row_idx, const float *Y, const int32_t *copy_idx, int B, int slab_rows, int ldy
 template <class SH, int ACT, int OUTK, bool STAMP = false, int TUNE = 0, bool BF = false>
 __global__ __launch_bounds__(RB_NT) void rowblock_kernel(GNN_RB_HEAD_PARAMS, RbParams p) {
     static_assert(!BF || SH::kL == 3 || SH::kL == 4, "the bf16 row-block kernel: nets of three and four layers");
-    p.slabs = slabs; p.W[1] = W1; p.row_idx = row_idx;
+    p.slabs = slabs; p.W[1] = W1; p.row_idx = row_idx; p.copy_idx = copy_idx;
     if constexpr (SH::kL > 0) p.W[SH::kL - 2] = Wlast; // (the instance for any layer count keeps the struct's own pointer)
     p.Y = Y; p.B = B; p.slab_rows = slab_rows; p.ldy = ldy;
     if constexpr (SH::is_static) {

@@ -8,7 +8,7 @@
 #include <cstdlib>
 #include <vector>
 using namespace gnn;
-#define RBHEAD(r) (r).slabs, (r).W[1], (r).W[2], (r).row_idx, (r).Y, (r).B, (r).slab_rows, (r).ldy // (GNN_RB_HEAD_PARAMS; build with -mllvm -amdgpu-kernarg-preload-count=16)
+#define RBHEAD(r) (r).slabs, (r).W[1], (r).W[2], (r).row_idx, (r).Y, (r).copy_idx, (r).B, (r).slab_rows, (r).ldy // (GNN_RB_HEAD_PARAMS; build with -mllvm -amdgpu-kernarg-preload-count=16)
 using SS = StaticShape<784, 300, 100, 10>;
 using RS = RbStaticShape<784, 300, 100, 10>;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
