@@ -12,6 +12,7 @@ cp "$SRC/stats_cfg45_bf16/run_kernel_stats.csv" "$DST/final_configs45_bf16_kerne
 python3 tools/pmc_summary.py "$SRC/pmc_fetch/run_counter_collection.csv" "$SRC/pmc_write/run_counter_collection.csv" > "$DST/pmc_traffic.json"
 python3 tools/sq_summary.py "$SRC/pmc_sq/run_counter_collection.csv" > "$DST/sq_counters.json"
 python3 tools/mfma_summary.py "$SRC/pmc_mfma/run_counter_collection.csv" "$SRC/pmc_mfma_cfg45/run_counter_collection.csv" > "$DST/mfma_counters.json"
+: > "$DST/final_step_trace_configs45.txt"   # (the loop below appends: one section per config and dtype)
 for c in 4 5; do for d in f32 bf16; do
   n=$(python3 - "$SRC/trace_cfg${c}_$d/run_kernel_trace.csv" <<'PY'
 import csv, sys
