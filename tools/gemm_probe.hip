@@ -12,15 +12,16 @@ using namespace gnn;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 static float *dA, *dB, *dC, *dAux, *dW, *dV;
+static int g_pad = 0; // GEMM_PROBE_PAD: extra elements on every leading dimension (is a power-of-two row stride a cost? mode 20)
 
 template <int BM, int BN, bool AK, bool BKC, int EPI, int WM, int NSTG, int BKT = 0>
 void run(const char *what, int M, int N, int K) {
     GemmParams p{};
-    p.A = dA; p.lda = AK ? K : M;
-    p.B = dB; p.ldb = BKC ? K : N;
-    p.C = dC; p.ldc = N;
+    p.A = dA; p.lda = (AK ? K : M) + g_pad;
+    p.B = dB; p.ldb = (BKC ? K : N) + g_pad;
+    p.C = dC; p.ldc = N + g_pad;
     p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
-    p.aux = dAux; p.ldaux = N; p.W = dW; p.V = dV; p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
+    p.aux = dAux; p.ldaux = N + g_pad; p.W = dW; p.V = dV; p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(WM * 128);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG, BKT>), grid, block, 0, 0, p);
@@ -39,11 +40,11 @@ void run(const char *what, int M, int N, int K) {
 template <bool AK, bool BKC, int EPI, int NW, int DEPTH>
 void runk(const char *what, int M, int N, int K) {
     GemmParams p{};
-    p.A = dA; p.lda = AK ? K : M;
-    p.B = dB; p.ldb = BKC ? K : N;
-    p.C = dC; p.ldc = N;
+    p.A = dA; p.lda = (AK ? K : M) + g_pad;
+    p.B = dB; p.ldb = (BKC ? K : N) + g_pad;
+    p.C = dC; p.ldc = N + g_pad;
     p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
-    p.aux = dAux; p.ldaux = N; p.W = dW; p.V = dV; p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
+    p.aux = dAux; p.ldaux = N + g_pad; p.W = dW; p.V = dV; p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
     dim3 grid(N / 32, M / 32), block(NW * 64);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_f32_wavek_kernel<AK, BKC, EPI, NW, DEPTH>), grid, block, 0, 0, p);
@@ -63,9 +64,9 @@ void runk(const char *what, int M, int N, int K) {
 template <bool AK, bool BKC, int EPI, int NW, int DEPTH>
 void check(int M, int N, int K) {
     GemmParams p{};
-    p.A = dA; p.lda = AK ? K : M;
-    p.B = dB; p.ldb = BKC ? K : N;
-    p.C = dC; p.ldc = N;
+    p.A = dA; p.lda = (AK ? K : M) + g_pad;
+    p.B = dB; p.ldb = (BKC ? K : N) + g_pad;
+    p.C = dC; p.ldc = N + g_pad;
     p.aux = dW; p.ldaux = N;
     p.M = M; p.N = N; p.K = K; p.m_true = M - 3; p.n_true = N - 5; p.act = 0;
     hipLaunchKernelGGL((gemm_f32_kernel<32, 32, AK, BKC, EPI, 2>), dim3(N / 32, M / 32), dim3(256), 0, 0, p);
@@ -88,11 +89,11 @@ void check(int M, int N, int K) {
 template <int BM, int BN, bool AK, bool BKC, int EPI, int NSTG = 2, int WM = 2>
 void runb(const char *what, int M, int N, int K) {
     GemmBf16Params p{};
-    p.A = reinterpret_cast<const __bf16 *>(dA); p.lda = AK ? K : M;
-    p.B = reinterpret_cast<const __bf16 *>(dB); p.ldb = BKC ? K : N;
-    p.C = dC; p.ldc = N; p.Cb = reinterpret_cast<__bf16 *>(dAux);
+    p.A = reinterpret_cast<const __bf16 *>(dA); p.lda = (AK ? K : M) + g_pad;
+    p.B = reinterpret_cast<const __bf16 *>(dB); p.ldb = (BKC ? K : N) + g_pad;
+    p.C = dC; p.ldc = N + g_pad; p.Cb = reinterpret_cast<__bf16 *>(dAux);
     p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
-    p.aux = dW; p.ldaux = N; p.W = dW; p.V = dV; p.Wb = reinterpret_cast<__bf16 *>(dAux); p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
+    p.aux = dW; p.ldaux = N + g_pad; p.W = dW; p.V = dV; p.Wb = reinterpret_cast<__bf16 *>(dAux); p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
     if (EPI == EPI_SGD) { p.C = nullptr; p.Cb = nullptr; }
     constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, AK, BKC>();
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -150,7 +151,8 @@ static void clock_under_load() {
 }
 
 int main(int argc, char **argv) {
-    const size_t n = (size_t)4096 * 2048 + 4096;
+    if (getenv("GEMM_PROBE_PAD")) g_pad = atoi(getenv("GEMM_PROBE_PAD"));
+    const size_t n = (size_t)4096 * (2048 + 256) + 4096;
     std::vector<float> h(n);
     for (size_t i = 0; i < n; i++) h[i] = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
     float **bufs[] = {&dA, &dB, &dC, &dAux, &dW, &dV};
@@ -175,6 +177,21 @@ int main(int argc, char **argv) {
             runb<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 1", 2048, 2048, 512);
             runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 2", 2048, 1024, 512);
             runb<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 2", 2048, 1024, 512);
+        }
+        return 0;
+    }
+    if (which == 20) {
+        printf("---- the production kernels of configs[3] / [4] with %d extra elements per row (each twice)\n", g_pad);
+        for (int rep = 0; rep < 2; rep++) {
+            runk<true, false, EPI_ACT, 4, 2>("cfg5 forward (wave-K)", 256, 1024, 1024);
+            runk<true, true, EPI_DACT, 4, 2>("cfg5 backward data (wave-K)", 256, 1024, 1024);
+            run<64, 64, true, false, EPI_ACT, 4, 1>("cfg4 forward 1", 512, 2048, 4096);
+            run<64, 64, true, true, EPI_DACT, 4, 1>("cfg4 backward data 1", 512, 2048, 2048);
+            run<128, 128, false, false, EPI_SGD, 2, 1>("cfg4 gradient + update 0", 4096, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 4, 1>("cfg4 gradient + update 1", 2048, 2048, 512);
+            runb<64, 64, true, false, EPI_ACT, 2, 4>("cfg4 bf16 forward 1", 512, 2048, 4096);
+            runb<64, 64, true, true, EPI_DACT, 2, 2>("cfg4 bf16 backward data 1", 512, 2048, 2048);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("cfg4 bf16 gradient + update 0", 4096, 2048, 512);
         }
         return 0;
     }
