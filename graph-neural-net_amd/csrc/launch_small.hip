@@ -196,7 +196,9 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
             else { r.X = h->next_a0; r.xcopy = h->xstage[h->xstage_cur ^ 1]; }
         }
         // (the head arguments: rowblock_kernel.h, GNN_RB_HEAD_PARAMS -- in this order)
-        const float *hd_W1 = r.W[1], *hd_Wl = r.W[h->L - 2];
+        const bool bf = h->dtype == GNN_DTYPE_BF16; // (the bf16 kernel takes its bf16 shadows' pointers in the two weight slots)
+        const float *hd_W1 = bf ? reinterpret_cast<const float *>(r.Wb[1]) : r.W[1];
+        const float *hd_Wl = bf ? reinterpret_cast<const float *>(r.Wb[h->L - 2]) : r.W[h->L - 2];
         void *args[] = {&r.slabs, &hd_W1, &hd_Wl, &r.row_idx, &r.Y, &r.copy_idx, &r.B, &r.slab_rows, &r.ldy, &r};
         const unsigned grid = (unsigned)(pad_up(B) / 4);
         TimerClass &tc = h->timers[GNN_K_MIDDLE];

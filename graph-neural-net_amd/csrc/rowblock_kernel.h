@@ -828,8 +828,14 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
 template <class SH, int ACT, int OUTK, bool STAMP = false, int TUNE = 0, bool BF = false>
 __global__ __launch_bounds__(RB_NT) void rowblock_kernel(GNN_RB_HEAD_PARAMS, RbParams p) {
     static_assert(!BF || SH::kL == 3 || SH::kL == 4, "the bf16 row-block kernel: nets of three and four layers");
-    p.slabs = slabs; p.W[1] = W1; p.row_idx = row_idx; p.copy_idx = copy_idx;
-    if constexpr (SH::kL > 0) p.W[SH::kL - 2] = Wlast; // (the instance for any layer count keeps the struct's own pointer)
+    p.slabs = slabs; p.row_idx = row_idx; p.copy_idx = copy_idx;
+    if constexpr (BF) { // (the bf16 kernel streams the bf16 shadows: THEIR pointers travel in the two weight slots)
+        p.Wb[1] = reinterpret_cast<const __bf16 *>(W1);
+        if constexpr (SH::kL > 0) p.Wb[SH::kL - 2] = reinterpret_cast<const __bf16 *>(Wlast);
+    } else {
+        p.W[1] = W1;
+        if constexpr (SH::kL > 0) p.W[SH::kL - 2] = Wlast; // (the instance for any layer count keeps the struct's own pointer)
+    }
     p.Y = Y; p.B = B; p.slab_rows = slab_rows; p.ldy = ldy;
     if constexpr (SH::is_static) {
         constexpr RbPlan m = SH::make(); // a LOCAL constexpr object: member accesses with constant indices fold to immediates

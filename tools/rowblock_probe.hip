@@ -9,6 +9,7 @@
 #include <vector>
 using namespace gnn;
 #define RBHEAD(r) (r).slabs, (r).W[1], (r).W[2], (r).row_idx, (r).Y, (r).copy_idx, (r).B, (r).slab_rows, (r).ldy // (GNN_RB_HEAD_PARAMS; build with -mllvm -amdgpu-kernarg-preload-count=16)
+#define RBHEAD_BF(r) (r).slabs, (const float *)(r).Wb[1], (const float *)(r).Wb[2], (r).row_idx, (r).Y, (r).copy_idx, (r).B, (r).slab_rows, (r).ldy
 using SS = StaticShape<784, 300, 100, 10>;
 using RS = RbStaticShape<784, 300, 100, 10>;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -86,10 +87,11 @@ int main(int argc, char **argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-44s %8.2f us per call\n", name, ms * 1000.f / n);
     };
-    auto stamps_of = [&](const char *name, auto kst) {
+    auto stamps_of = [&](const char *name, auto kst, bool bf = false) {
         CK(hipFuncSetAttribute((const void *)kst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
         CK(hipMemsetAsync(stamps, 0, 4096 * 16 * 8, s));
-        hipLaunchKernelGGL(kst, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb);
+        if (bf) hipLaunchKernelGGL(kst, grid, dim3(RB_NT), ldsr, s, RBHEAD_BF(rb), rb);
+        else hipLaunchKernelGGL(kst, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb);
         CK(hipStreamSynchronize(s));
         std::vector<unsigned long long> hs((size_t)32 * 16 * 9);
         CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
@@ -126,5 +128,18 @@ int main(int argc, char **argv) {
     VARIANT(0x300000); // both
     VARIANT(0);
     time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
+    { // the bf16 instance (BF): time and stamps only (operands: the f32 weights rounded; outputs not compared here -- tests/test_bf16_gpu.py does)
+        __bf16 *Wb; CK(hipMalloc(&Wb, np * 2));
+        std::vector<__bf16> hb(np);
+        for (size_t i = 0; i < np; i++) hb[i] = (__bf16)hw[i];
+        CK(hipMemcpy(Wb, hb.data(), np * 2, hipMemcpyHostToDevice));
+        for (int l = 1; l < 3; l++) { rb.Wb[l] = Wb + woff[l]; CK(hipMalloc(&rb.actb[l], (size_t)Bp * ld[l] * 2)); }
+        for (int l = 1; l < L; l++) CK(hipMalloc(&rb.deltab[l], (size_t)Bp * ld[l] * 2));
+        auto kb = rowblock_kernel<RS, 0, 0, false, 0, true>;
+        CK(hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+        time_it("rowblock<static, bf16>", 500, [&]() { hipLaunchKernelGGL(kb, grid, dim3(RB_NT), ldsr, s, RBHEAD_BF(rb), rb); });
+        stamps_of("bf16", rowblock_kernel<RS, 0, 0, true, 0, true>, true);
+        time_it("rowblock<static> TUNE=0 (f32 again)", 500, [&]() { hipLaunchKernelGGL(k_new, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb); });
+    }
     return 0;
 }
