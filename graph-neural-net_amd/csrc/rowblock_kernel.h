@@ -222,9 +222,12 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     //   * every load OUTSIDE that block is unconditional (clamped address, never `cond ? offset : 0` on a wave-uniform
     //     condition): after a branch that contains a load the compiler's wait-count pass drains the whole queue
     //     (s_waitcnt vmcnt(0)) at the next use of anything loaded.
-    constexpr int RB_PF = 2;                       // weight units requested ahead of the one being multiplied
-    constexpr int PF0 = (TUNE & 7) ? (TUNE & 7) : 2; // units requested before the slabs
-    constexpr bool W_FIRST = (TUNE & 8) == 0;      // the first weight units in front of the slabs in every wave's queue
+    // (Re-measured after the head arguments moved into SGPRs -- the first loads now issue ~500 cycles earlier and the best order
+    //  changed with it: the slabs first and ONE weight unit ahead, 6.22 us per launch; two units ahead 6.30; the weights in front of the
+    //  slabs, the order of the builds before, 6.30 / 6.50 with one / two units; three units 7.44.  tools/rowblock_probe 128 1.)
+    constexpr int RB_PF = (TUNE & 0x600) ? ((TUNE >> 9) & 3) : 2; // weight units requested ahead of the one being multiplied
+    constexpr int PF0 = (TUNE & 7) ? (TUNE & 7) : 1; // units requested before A_1 is formed
+    constexpr bool W_FIRST = (TUNE & 8) != 0;      // (probe) the first weight units in FRONT of the slabs in every wave's queue
     // (the row index of a sampled batch's expected row is a DEPENDENT load: issued first)
     const int qy = m.ld[Lm] >> 2; // 4
     const int y_e = RB_NT - 1 - t, y_r = y_e / qy, y_q = y_e - y_r * qy; // the expected rows: the LAST threads

@@ -121,6 +121,10 @@ int main(int argc, char **argv) {
     time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
     time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb); });
     VARIANT(0);   // weights first (2 units), images of waves 4-7 deferred
+    if (argc > 2) { // prefetch variants (TUNE & 7 = weight units requested before A_1 is formed, default 1; 8 = weights in front of the slabs; 0x200 / 0x600 = RB_PF 1 / 3; 128 = no early image copies)
+        VARIANT(2); VARIANT(0); VARIANT(9); VARIANT(10); VARIANT(0); VARIANT(0x200); VARIANT(0x600); VARIANT(0); VARIANT(0x202); VARIANT(128); VARIANT(0);
+        return 0;
+    }
     VARIANT(0x400000); // the sampled batch's row copy compiled out
     VARIANT(0);
     VARIANT(0x100000); // NO weight stream (constants instead of W_1's loads; wrong results): what it costs
