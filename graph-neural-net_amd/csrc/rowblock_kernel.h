@@ -228,6 +228,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     constexpr int RB_PF = (TUNE & 0x600) ? ((TUNE >> 9) & 3) : 2; // weight units requested ahead of the one being multiplied
     constexpr int PF0 = (TUNE & 7) ? (TUNE & 7) : 1; // units requested before A_1 is formed
     constexpr bool W_FIRST = (TUNE & 8) != 0;      // (probe) the first weight units in FRONT of the slabs in every wave's queue
+    constexpr int PF1 = (TUNE & 0x800) ? PF0 + RB_PF : PF0; // (probe) units requested by the time of the A_1 barrier: the product's first RB_PF units right in front of it
     // (the row index of a sampled batch's expected row is a DEPENDENT load: issued first)
     const int qy = m.ld[Lm] >> 2; // 4
     const int y_e = RB_NT - 1 - t, y_r = y_e / qy, y_q = y_e - y_r * qy; // the expected rows: the LAST threads
@@ -350,6 +351,12 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
         for (int uu = 0; uu < UPW1; uu++)
             if (uu < PF0 && uu < nu_1) to_image_1(uu);
     }
+    if constexpr (UPW1 > 0 && PF1 > PF0) {
+#pragma unroll
+        for (int uu = PF0; uu < UPW1; uu++)
+            if (uu < PF1) load_unit_1(uu);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // A_1 for the tile kernel: stored LAST.  The memory counter counts stores too, and the copies above wait for "all but
     // the youngest request" (what a wave without slabs needs): with the store in front of them the slab waves sat out its
     // round trip to L2 in front of the barrier.
@@ -425,10 +432,10 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
             // image for the backward product (13 cycles of the LDS store path per write, under the matrix pipe's 128 per unit)
 #pragma unroll
             for (int uu = 0; uu < UPW1; uu++) {
-                if (uu + RB_PF >= PF0 && uu + RB_PF < UPW1) load_unit_1(uu + RB_PF);
-                if (uu == 0) { // (PF0 < RB_PF: catch up)
+                if (uu + RB_PF >= PF1 && uu + RB_PF < UPW1) load_unit_1(uu + RB_PF);
+                if (uu == 0) { // (PF1 < RB_PF: catch up)
 #pragma unroll
-                    for (int v = PF0; v < RB_PF && v < UPW1; v++) load_unit_1(v);
+                    for (int v = PF1; v < RB_PF && v < UPW1; v++) load_unit_1(v);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (uu < nu) {
