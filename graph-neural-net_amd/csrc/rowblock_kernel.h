@@ -346,7 +346,12 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     // the weight units requested in phase 0 have landed in front of the slabs (or this wave has no slabs and nothing else to
     // do until A_1 exists): their rows go to the LDS image NOW, in time the wave would spend waiting at the barrier
     constexpr bool EARLY_IMG = (TUNE & 128) == 0;
-    if (EARLY_IMG && UPW1 > 0 && Lm >= 3) {
+    // The waves that sum slabs do not wait for their first weight unit in front of the barrier: no early copy for them (the
+    // unit's rows go to the image inside the product like the others'), and A_1's store moves behind the product so that the
+    // unit's wait does not stand behind the store's round trip (6.26 -> 6.19 us; probe bit 0x1000 = every wave copies early)
+    constexpr bool SLAB_NOWAIT = (TUNE & 0x1000) == 0;
+    const bool early_here = !SLAB_NOWAIT || wave * 64 >= 4 * q1; // (wave-uniform)
+    if (EARLY_IMG && early_here && UPW1 > 0 && Lm >= 3) {
 #pragma unroll
         for (int uu = 0; uu < UPW1; uu++)
             if (uu < PF0 && uu < nu_1) to_image_1(uu);
@@ -360,10 +365,13 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     // A_1 for the tile kernel: stored LAST.  The memory counter counts stores too, and the copies above wait for "all but
     // the youngest request" (what a wave without slabs needs): with the store in front of them the slab waves sat out its
     // round trip to L2 in front of the barrier.
-    if (a1_goff != 0xffffffffu) {
-        if (BF) *reinterpret_cast<m4_bf16x4 *>(reinterpret_cast<char *>(p.actb[1]) + (size_t)(a1_goff * 2u)) = (m4_bf16x4){(__bf16)a1v[0], (__bf16)a1v[1], (__bf16)a1v[2], (__bf16)a1v[3]};
-        else *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(p.act[1]) + (size_t)(a1_goff * 4u)) = a1v;
-    }
+    auto store_a1 = [&]() {
+        if (a1_goff != 0xffffffffu) {
+            if (BF) *reinterpret_cast<m4_bf16x4 *>(reinterpret_cast<char *>(p.actb[1]) + (size_t)(a1_goff * 2u)) = (m4_bf16x4){(__bf16)a1v[0], (__bf16)a1v[1], (__bf16)a1v[2], (__bf16)a1v[3]};
+            else *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(p.act[1]) + (size_t)(a1_goff * 4u)) = a1v;
+        }
+    };
+    if (!SLAB_NOWAIT || !(UPW1 > 0 && Lm >= 3)) store_a1();
     GNN_RB_WSTAMP(0); // this wave at the A_1 barrier
     __syncthreads();
     GNN_RB_STAMP(1);
@@ -443,11 +451,12 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
                     for (int tt = 0; tt < 4; tt++)
 #pragma unroll
                         for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(av1[uu][tt], w1[uu][tt][j], acc[j], 0, 0, 0);
-                    if (!(EARLY_IMG && uu < PF0) && (!DEFER || wave < n_sum_waves)) to_image_1(uu);
+                    if (!(EARLY_IMG && early_here && uu < PF0) && (!DEFER || wave < n_sum_waves)) to_image_1(uu);
                 }
                 if (STAMP && uu == 1) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); GNN_RB_WSTAMP(6); } // units 0, 1 multiplied
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (SLAB_NOWAIT) store_a1();
         } else {
             if (l + 1 == Lm - 1 && wave < 4) load_tail_weights(); // (as in the branch above)
             // later layers (nets of five and more layers): the slice is loaded here, RB_MAXU units at a time
@@ -727,7 +736,7 @@ __device__ __forceinline__ void rowblock_body(const RbPlan &m, RbParams &p) {
     else if (DEFER && UPW1 > 0 && Lm >= 3) {
 #pragma unroll
         for (int uu = 0; uu < UPW1; uu++)
-            if (!(EARLY_IMG && uu < PF0) && uu < nu_1) to_image_1(uu);
+            if (!(EARLY_IMG && early_here && uu < PF0) && uu < nu_1) to_image_1(uu);
     }
     if (wave >= 4 && x_copy) { // (wave-uniform) wave 4 + r: input row r of this block
         // (the row's index was fetched at the top; every load of the row in flight before the first store: as a loop of

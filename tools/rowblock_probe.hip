@@ -122,6 +122,7 @@ int main(int argc, char **argv) {
     time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb); });
     VARIANT(0);   // weights first (2 units), images of waves 4-7 deferred
     if (argc > 2) { // prefetch variants (TUNE & 7 = weight units requested before A_1 is formed, default 1; 8 = weights in front of the slabs; 0x200 / 0x600 = RB_PF 1 / 3; 128 = no early image copies)
+        if (atoi(argv[2]) == 4) { VARIANT(0); VARIANT(0x1000); VARIANT(0); VARIANT(0x1002); VARIANT(0x1000); VARIANT(0); return 0; }
         if (atoi(argv[2]) == 3) { VARIANT(0); VARIANT(0x800); VARIANT(0); VARIANT(0xa00); VARIANT(0xe00); VARIANT(0); VARIANT(0x802); return 0; }
         if (atoi(argv[2]) == 2) { VARIANT(0); VARIANT(32); VARIANT(0); VARIANT(64); VARIANT(0); VARIANT(96); VARIANT(16); VARIANT(0); return 0; }
         VARIANT(2); VARIANT(0); VARIANT(9); VARIANT(10); VARIANT(0); VARIANT(0x200); VARIANT(0x600); VARIANT(0); VARIANT(0x202); VARIANT(128); VARIANT(0);
