@@ -122,6 +122,7 @@ int main(int argc, char **argv) {
     time_it("rowblock<runtime shape>", 500, [&]() { hipLaunchKernelGGL(k_new_rt, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb); });
     VARIANT(0);   // weights first (2 units), images of waves 4-7 deferred
     if (argc > 2) { // prefetch variants (TUNE & 7 = weight units requested before A_1 is formed, default 1; 8 = weights in front of the slabs; 0x200 / 0x600 = RB_PF 1 / 3; 128 = no early image copies)
+        if (atoi(argv[2]) == 5) goto bf16_block;
         if (atoi(argv[2]) == 4) { VARIANT(0); VARIANT(0x1000); VARIANT(0); VARIANT(0x1002); VARIANT(0x1000); VARIANT(0); return 0; }
         if (atoi(argv[2]) == 3) { VARIANT(0); VARIANT(0x800); VARIANT(0); VARIANT(0xa00); VARIANT(0xe00); VARIANT(0); VARIANT(0x802); return 0; }
         if (atoi(argv[2]) == 2) { VARIANT(0); VARIANT(32); VARIANT(0); VARIANT(64); VARIANT(0); VARIANT(96); VARIANT(16); VARIANT(0); return 0; }
@@ -135,6 +136,7 @@ int main(int argc, char **argv) {
     VARIANT(0x300000); // both
     VARIANT(0);
     time_it("middle4<static, slabs> (16 waves)", 500, [&]() { hipLaunchKernelGGL(k_old, grid, dim3(1024), lds4, s, m4); });
+bf16_block:
     { // the bf16 instance (BF): time and stamps only (operands: the f32 weights rounded; outputs not compared here -- tests/test_bf16_gpu.py does)
         __bf16 *Wb; CK(hipMalloc(&Wb, np * 2));
         std::vector<__bf16> hb(np);
@@ -146,6 +148,12 @@ int main(int argc, char **argv) {
         CK(hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
         time_it("rowblock<static, bf16>", 500, [&]() { hipLaunchKernelGGL(kb, grid, dim3(RB_NT), ldsr, s, RBHEAD_BF(rb), rb); });
         stamps_of("bf16", rowblock_kernel<RS, 0, 0, true, 0, true>, true);
+#define BFVARIANT(T) do { \
+            auto kv = rowblock_kernel<RS, 0, 0, false, T, true>; \
+            CK(hipFuncSetAttribute((const void *)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr)); \
+            time_it("rowblock<static, bf16> TUNE=" #T, 500, [&]() { hipLaunchKernelGGL(kv, grid, dim3(RB_NT), ldsr, s, RBHEAD_BF(rb), rb); }); \
+        } while (0)
+        if (argc > 2) { BFVARIANT(0); BFVARIANT(2); BFVARIANT(0); BFVARIANT(9); BFVARIANT(10); BFVARIANT(0); BFVARIANT(0x1000); BFVARIANT(0x200); BFVARIANT(0x600); BFVARIANT(0); }
         time_it("rowblock<static> TUNE=0 (f32 again)", 500, [&]() { hipLaunchKernelGGL(k_new, grid, dim3(RB_NT), ldsr, s, RBHEAD(rb), rb); });
     }
     return 0;
