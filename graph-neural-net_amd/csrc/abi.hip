@@ -1,6 +1,8 @@
 // abi.hip -- the C ABI of include/gnn_mlp.h for ONE net on ONE GPU: argument checks, staging of host rows,
 // the handle's lifetime.  What a step is made of: plan.hip; kernels: launch_*.hip.
 #include "handle.h"
+
+#include <chrono>
 #include "java_random.h"
 
 #include <cmath>
@@ -482,7 +484,11 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
     }
     for (; s < n_steps; s++) {
         const int64_t row0 = ((first / B + s) % nb) * B;
-        if (s + 1 < n_steps) hint_range(h, ((first / B + s + 1) % nb) * B, B); // the step's tile kernel also starts the next step
+        // the step's tile kernel also starts the next step -- the LAST step's too: it prepares the batch that follows the range in
+        // the data set, so that a caller who walks the data set call by call (an epoch, or a slice of one, per call) keeps the
+        // two-launch chain across calls instead of opening every call with a forward-only launch (the sums are used only if the
+        // next gradient is on exactly those rows with the weights as this step leaves them: slabs_hold)
+        hint_range(h, ((first / B + s + 1) % nb) * B, B);
         TRY(step_on_rows(h, h->DX + (size_t)row0 * h->ld[0], h->DY + (size_t)row0 * h->ld[h->L - 1], B, step,
                          momentum, true));
     }
@@ -615,7 +621,23 @@ int gnn_mlp_recover_stream(gnn_mlp_t *h) { return guarded([&]() -> int {
 
 int gnn_mlp_synchronize(gnn_mlp_t *h) { return guarded([&]() -> int {
     TRY(check_handle(h));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    // A caller that waits for a few hundred microseconds of kernels should not pay an interrupt's wake-up (tens of
+    // microseconds) on top: the stream is polled for a bounded time first, then the call blocks.
+    // (hipErrorNotReady may be left behind as the thread's "last error", which check_launches reads: an error of an earlier
+    //  launch is moved to the handle first, and the polling's own status is cleared afterwards)
+    const hipError_t before = hipGetLastError();
+    if (before != hipSuccess && h->launch_error == hipSuccess) h->launch_error = before;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool done = false;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(h->stream);
+        if (e == hipSuccess) { done = true; break; }
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); return fail(GNN_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e)); }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
+        __builtin_ia32_pause();
+    }
+    (void)hipGetLastError();
+    if (!done) HIP_TRY(hipStreamSynchronize(h->stream));
     return GNN_OK;
 }); }
 
