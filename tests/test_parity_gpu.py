@@ -809,3 +809,44 @@ def test_long_runs_repeat_bitwise(gnn, dtype_name):
         assert np.isfinite(w[0]).all()
         assert np.array_equal(w[0], w[1])
     assert forced or nets[0].step_launches == 2
+
+
+def test_train_range_calls_continue_the_chain(gnn):
+    """A range's last step also prepares the batch that follows it in the data set (abi.hip, gnn_mlp_train_range): calls
+    that walk the data set one after the other give the weights of ONE call bitwise -- also when the prepared sums are
+    not the ones the next call needs (another start row), when the weights are replaced in between (the sums are dropped)
+    and when an inference call sits between two training calls."""
+    dims, B, nb = [784, 300, 100, 10], 128, 5
+    X, Y = make_batch(dims, B * nb, seed=83, sparse=True)
+    nets = [gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B) for _ in range(4)]
+    for net in nets:
+        net.upload_dataset(X, Y)
+    one, cut, jump, swapped = nets
+    one.train_range(0, B, 9, 0.0125, 0.9)
+    cut.train_range(0, B, 4, 0.0125, 0.9)
+    cut.propagate(X[:7])                                      # inference between two training calls
+    cut.train_range(4 * B, B, 3, 0.0125, 0.9)                 # continues where the first call stopped (batch 4, then 0, 1)
+    cut.train_range(2 * B, B, 2, 0.0125, 0.9)
+    assert np.array_equal(one.get_weights(), cut.get_weights())
+    assert np.array_equal(one.get_momentum(), cut.get_momentum())
+    # a call that does NOT start where the last one stopped: the prepared sums are of batch 3, the call wants batch 1
+    jump.train_range(0, B, 3, 0.0125, 0.9)
+    jump.train_range(B, B, 2, 0.0125, 0.9)
+    ref = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    ref.upload_dataset(X, Y)
+    for b in (0, 1, 2, 1, 2):
+        ref.gradient_step_range(b * B, B, 0.0125, 0.9)
+    assert np.array_equal(jump.get_weights(), ref.get_weights())
+    # weights replaced between two calls: the sums prepared with the old weights must not be used
+    swapped.train_range(0, B, 2, 0.0125, 0.9)
+    w = swapped.get_weights() * 0.5
+    swapped.set_weights(w)
+    swapped.train_range(2 * B, B, 2, 0.0125, 0.9)
+    ref2 = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    ref2.upload_dataset(X, Y)
+    ref2.train_range(0, B, 2, 0.0125, 0.9)
+    ref2.set_weights(w)
+    for b in (2, 3):
+        ref2.gradient_step_range(b * B, B, 0.0125, 0.9)
+    assert np.array_equal(swapped.get_weights(), ref2.get_weights())
+
