@@ -78,7 +78,8 @@ constexpr size_t gemm_bf16_lds_bytes() {
 
 // WM: wave rows (waves are WM x 2, WM * 128 threads); WM = 4 puts eight waves on a tile (see gemm_f32_kernel)
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int NSTG = 2, int WM = 2>
-__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmBf16Params p) {
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAMS(__bf16), GemmBf16Params p) {
+    GNN_GEMM_TAKE_HEAD(p);
     constexpr int NT = WM * 128;
     constexpr int BK = GemmBf16Depth<BM>::BK;
     constexpr int TM = BM / (WM * 16), TN = BN / 32; // 16x16 MFMA tiles per wave (waves are WM x 2)

@@ -29,8 +29,11 @@ constexpr int WK_LDP = 36;  // partial tiles [32][32 + 4]
 constexpr int WK_WAVE_FLOATS = 2 * WK_CH * WK_LDT; // per wave: two operand images; the partial tile reuses them
 static_assert(32 * WK_LDP <= WK_WAVE_FLOATS, "the partial tile reuses the wave's operand images");
 
-template <bool A_KC, bool B_KC, int EPI, int NW, int DEPTH>
-__global__ __launch_bounds__(NW * 64) void gemm_f32_wavek_kernel(GemmParams p) {
+// (GNN_GEMM_HEAD_PARAMS, kernels.h: the main loop's first values preloaded into SGPRs.  HEAD = false: the struct's own copies --
+//  tools/gemm_probe 21 compares the two: 8.85 against 9.07 us forward, 10.0 against 10.2 backward at 256 x 1024 x 1024.)
+template <bool A_KC, bool B_KC, int EPI, int NW, int DEPTH, bool HEAD = true>
+__global__ __launch_bounds__(NW * 64) void gemm_f32_wavek_kernel(GNN_GEMM_HEAD_PARAMS(float), GemmParams p) {
+    if constexpr (HEAD) GNN_GEMM_TAKE_HEAD(p);
     __shared__ __attribute__((aligned(16))) float lds[NW * WK_WAVE_FLOATS];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);

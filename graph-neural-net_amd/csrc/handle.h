@@ -207,7 +207,7 @@ struct ScopedTimer {
 // Launch with the dispatch's OWN begin/end timestamps (hipExtLaunchKernel start/stop events): the
 // elapsed time between them is the kernel's execution time, the same quantity rocprofv3's
 // kernel trace reports -- unlike events recorded around a launch, which add marker overhead.
-template <class K, class P> void launch_timed(gnn_mlp *h, int cls, K kernel, dim3 grid, dim3 block, size_t lds, const P &params) {
+template <class K, class... P> void launch_timed(gnn_mlp *h, int cls, K kernel, dim3 grid, dim3 block, size_t lds, const P &...params) {
     if (h->timing && cls >= 0) {
         TimerClass &t = h->timers[cls];
         if (t.used < 8192) {
@@ -217,12 +217,12 @@ template <class K, class P> void launch_timed(gnn_mlp *h, int cls, K kernel, dim
             }
             if (t.used < t.start.size()) {
                 const size_t slot = t.used++;
-                hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, h->stream, t.start[slot], t.stop[slot], 0, params);
+                hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, h->stream, t.start[slot], t.stop[slot], 0, params...);
                 return;
             }
         }
     }
-    hipLaunchKernelGGL(kernel, grid, block, lds, h->stream, params);
+    hipLaunchKernelGGL(kernel, grid, block, lds, h->stream, params...);
 }
 
 // Zero-filled device allocation.  The fill is enqueued on the HANDLE's stream: that stream is

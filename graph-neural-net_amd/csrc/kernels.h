@@ -80,6 +80,13 @@ enum Epi {
     EPI_SGD = 3          // v = step_over_b*acc + mu*V; W -= v; V = v   (SCE:333-339 fused into G_l)
 };
 
+// The values a GEMM kernel's main loop starts from travel AHEAD of its parameter struct: leading scalar / pointer arguments are
+// preloaded into SGPRs by the dispatch (-amdgpu-kernarg-preload-count, build.py), so the first operand loads do not wait for a
+// scalar-cache miss on the kernel-argument segment -- 0.2 us per launch (tools/gemm_probe 21; rowblock_kernel.h, GNN_RB_HEAD_PARAMS).
+// The struct's own copies are overwritten from them; a launch passes GNN_GEMM_HEAD_ARGS(p), p.
+#define GNN_GEMM_HEAD_PARAMS(T) const T *hd_A, const T *hd_B, int hd_lda, int hd_ldb, int hd_M, int hd_N, int hd_K
+#define GNN_GEMM_TAKE_HEAD(p) do { (p).A = hd_A; (p).B = hd_B; (p).lda = hd_lda; (p).ldb = hd_ldb; (p).M = hd_M; (p).N = hd_N; (p).K = hd_K; } while (0)
+#define GNN_GEMM_HEAD_ARGS(p) (p).A, (p).B, (p).lda, (p).ldb, (p).M, (p).N, (p).K
 struct GemmParams {
     const float *A; int lda;
     const float *B; int ldb;
@@ -101,7 +108,8 @@ struct GemmParams {
 constexpr int gemm_f32_stages(int BM, int BN) { return 1; }
 template <bool B> struct BoolC { static constexpr bool value = B; };
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2, int NSTG = gemm_f32_stages(BM, BN), int BK_ = 0>
-__global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GNN_GEMM_HEAD_PARAMS(float), GemmParams p) {
+    GNN_GEMM_TAKE_HEAD(p);
     constexpr int NT = WM * 128;
     // k depth of a staged tile: small tiles do few MFMAs per wave per k -- more K per barrier pair, and per prefetch distance
     // (32 x 32: 128 deep measured 26.5 us against 29.2 us at 64 on 512 x 1024 x 2048)

@@ -19,7 +19,7 @@ void launch_gemm_bf16_t(gnn_mlp *h, int cls, const GemmBf16Params &p) {
         }
         opted_in = true;
     }
-    launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, 2, WM>, dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(WM * 128), lds, p);
+    launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, 2, WM>, dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(WM * 128), lds, GNN_GEMM_HEAD_ARGS(p), p);
 }
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {

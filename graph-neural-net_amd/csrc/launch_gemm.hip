@@ -12,7 +12,7 @@ namespace host {
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2>
 void launch_gemm_t(gnn_mlp *h, int cls, const GemmParams &p) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-    launch_timed(h, cls, gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, WM>, grid, dim3(WM * 128), 0, p);
+    launch_timed(h, cls, gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, WM>, grid, dim3(WM * 128), 0, GNN_GEMM_HEAD_ARGS(p), p);
 }
 
 // tile edge: keep >= ~256 workgroups in flight where the problem allows it (256 CUs)
@@ -28,7 +28,7 @@ int pick_tile(int M, int N) {
 bool wavek_fits(int M, int N, int K) { return M % 32 == 0 && N % 32 == 0 && K >= 128; }
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm_wavek(gnn_mlp *h, int cls, const GemmParams &p) {
-    launch_timed(h, cls, gemm_f32_wavek_kernel<A_KC, B_KC, EPI, 4, 2>, dim3(p.N / 32, p.M / 32), dim3(256), 0, p);
+    launch_timed(h, cls, gemm_f32_wavek_kernel<A_KC, B_KC, EPI, 4, 2>, dim3(p.N / 32, p.M / 32), dim3(256), 0, GNN_GEMM_HEAD_ARGS(p), p);
 }
 
 template <bool A_KC, bool B_KC, int EPI>

@@ -24,11 +24,11 @@ void run(const char *what, int M, int N, int K) {
     p.aux = dAux; p.ldaux = N + g_pad; p.W = dW; p.V = dV; p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(WM * 128);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG, BKT>), grid, block, 0, 0, p);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG, BKT>), grid, block, 0, 0, GNN_GEMM_HEAD_ARGS(p), p);
     CK(hipDeviceSynchronize());
     const int iters = 30;
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG, BKT>), grid, block, 0, 0, p);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM, NSTG, BKT>), grid, block, 0, 0, GNN_GEMM_HEAD_ARGS(p), p);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
@@ -37,7 +37,7 @@ void run(const char *what, int M, int N, int K) {
     fflush(stdout);
 }
 
-template <bool AK, bool BKC, int EPI, int NW, int DEPTH>
+template <bool AK, bool BKC, int EPI, int NW, int DEPTH, bool HEAD = true>
 void runk(const char *what, int M, int N, int K) {
     GemmParams p{};
     p.A = dA; p.lda = (AK ? K : M) + g_pad;
@@ -47,11 +47,11 @@ void runk(const char *what, int M, int N, int K) {
     p.aux = dAux; p.ldaux = N + g_pad; p.W = dW; p.V = dV; p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
     dim3 grid(N / 32, M / 32), block(NW * 64);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_f32_wavek_kernel<AK, BKC, EPI, NW, DEPTH>), grid, block, 0, 0, p);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_f32_wavek_kernel<AK, BKC, EPI, NW, DEPTH, HEAD>), grid, block, 0, 0, GNN_GEMM_HEAD_ARGS(p), p);
     CK(hipDeviceSynchronize());
     const int iters = 30;
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_f32_wavek_kernel<AK, BKC, EPI, NW, DEPTH>), grid, block, 0, 0, p);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_f32_wavek_kernel<AK, BKC, EPI, NW, DEPTH, HEAD>), grid, block, 0, 0, GNN_GEMM_HEAD_ARGS(p), p);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
@@ -69,9 +69,9 @@ void check(int M, int N, int K) {
     p.C = dC; p.ldc = N + g_pad;
     p.aux = dW; p.ldaux = N;
     p.M = M; p.N = N; p.K = K; p.m_true = M - 3; p.n_true = N - 5; p.act = 0;
-    hipLaunchKernelGGL((gemm_f32_kernel<32, 32, AK, BKC, EPI, 2>), dim3(N / 32, M / 32), dim3(256), 0, 0, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<32, 32, AK, BKC, EPI, 2>), dim3(N / 32, M / 32), dim3(256), 0, 0, GNN_GEMM_HEAD_ARGS(p), p);
     p.C = dAux;
-    hipLaunchKernelGGL((gemm_f32_wavek_kernel<AK, BKC, EPI, NW, DEPTH>), dim3(N / 32, M / 32), dim3(NW * 64), 0, 0, p);
+    hipLaunchKernelGGL((gemm_f32_wavek_kernel<AK, BKC, EPI, NW, DEPTH>), dim3(N / 32, M / 32), dim3(NW * 64), 0, 0, GNN_GEMM_HEAD_ARGS(p), p);
     std::vector<float> a((size_t)M * N), b((size_t)M * N);
     CK(hipMemcpy(a.data(), dC, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), dAux, b.size() * 4, hipMemcpyDeviceToHost));
     double md = 0, mx = 0; size_t bad = 0, first = 0;
@@ -99,11 +99,11 @@ void runb(const char *what, int M, int N, int K) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(WM * 128);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG, WM>), grid, block, lds, 0, p);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG, WM>), grid, block, lds, 0, GNN_GEMM_HEAD_ARGS(p), p);
     CK(hipDeviceSynchronize());
     const int iters = 30;
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG, WM>), grid, block, lds, 0, p);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG, WM>), grid, block, lds, 0, GNN_GEMM_HEAD_ARGS(p), p);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
@@ -138,7 +138,7 @@ static void clock_under_load() {
         CK(hipEventRecord(e0, sa));
         const int iters = 300;
         for (int i = 0; i < iters; i++)
-            hipLaunchKernelGGL((gemm_f32_kernel<128, 128, false, false, EPI_STORE, 2>), dim3(N / 128, M / 128), dim3(256), 0, sa, p);
+            hipLaunchKernelGGL((gemm_f32_kernel<128, 128, false, false, EPI_STORE, 2>), dim3(N / 128, M / 128), dim3(256), 0, sa, GNN_GEMM_HEAD_ARGS(p), p);
         CK(hipEventRecord(e1, sa));
         hipLaunchKernelGGL(clock_watch, dim3(1), dim3(64), 0, sb, d, 1000000ull); // 10 ms inside the ~25 ms of GEMMs
         CK(hipStreamSynchronize(sb)); CK(hipStreamSynchronize(sa));
@@ -177,6 +177,16 @@ int main(int argc, char **argv) {
             runb<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 1", 2048, 2048, 512);
             runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 2", 2048, 1024, 512);
             runb<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 2", 2048, 1024, 512);
+        }
+        return 0;
+    }
+    if (which == 21) {
+        printf("---- wave-K kernel: main-loop arguments preloaded (head) against read from the struct (each pair three times)\n");
+        for (int rep = 0; rep < 3; rep++) {
+            runk<true, false, EPI_ACT, 4, 2, true>("cfg5 forward, head args", 256, 1024, 1024);
+            runk<true, false, EPI_ACT, 4, 2, false>("cfg5 forward, struct", 256, 1024, 1024);
+            runk<true, true, EPI_DACT, 4, 2, true>("cfg5 backward data, head args", 256, 1024, 1024);
+            runk<true, true, EPI_DACT, 4, 2, false>("cfg5 backward data, struct", 256, 1024, 1024);
         }
         return 0;
     }
