@@ -222,17 +222,23 @@ def other_configs():
     bc = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bc)
     out = {}
-    for name, key, dtype, steps, graph in [("configs[0] f32", "1", "f32", 1000, False),
-                                           ("configs[3] f32", "4", "f32", 30, False), ("configs[3] bf16", "4", "bf16", 50, False),
-                                           ("configs[4] f32 eager", "5", "f32", 80, False),
-                                           ("configs[4] f32 hipGraph", "5", "f32", 160, True),
-                                           ("configs[4] bf16", "5", "bf16", 80, False)]:
+    # (name, config key, dtype, steps, hipGraph, resident batches, GeneralNeuralNet (inner, last) or None)
+    # configs[4]: SIXTEEN batches resident, so that one graph launch carries 16 steps (112 kernel nodes) -- with 4 (round 3) a
+    # launch carried 28 nodes and its cost was spread over 4 steps only: the captured line read 8 % SLOWER than the eager one.
+    for name, key, dtype, steps, graph, nb, general in [
+            ("configs[0] f32", "1", "f32", 1000, False, 4, None),
+            ("configs[1] GeneralNeuralNet sigmoid", "2", "f32", 1000, False, 4, ("sigmoid", "sigmoid")),
+            ("configs[1] GeneralNeuralNet leaky_relu/sigmoid", "2", "f32", 1000, False, 4, ("leaky_relu", "sigmoid")),
+            ("configs[3] f32", "4", "f32", 30, False, 4, None), ("configs[3] bf16", "4", "bf16", 50, False, 4, None),
+            ("configs[4] f32 eager", "5", "f32", 160, False, 16, None),
+            ("configs[4] f32 hipGraph", "5", "f32", 160, True, 16, None),
+            ("configs[4] bf16", "5", "bf16", 160, False, 16, None)]:
         try:
-            line = bc.run(key, dtype, steps, graph=graph, n_batches=4, timed_kernels=False)
+            line = bc.run(key, dtype, steps, graph=graph, n_batches=nb, timed_kernels=False, general=general)
             r = line["roofline"]
             out[name] = {"workload": line["config"]["workload"], "samples_per_s": line["value"], "us_per_step": round(line["ms_per_step"] * 1e3, 2),
                          "us_per_step_events": line.get("us_per_step_events"), "steps": steps, "dtype": dtype,
-                         "hipgraph": graph, "bound": r["bound"], "mfma_frac": r["mfma_frac"], "hbm_frac": r["hbm_frac"]}
+                         "hipgraph": graph, "batches_resident": nb, "bound": r["bound"], "mfma_frac": r["mfma_frac"], "hbm_frac": r["hbm_frac"]}
         except Exception as e:   # a config that fails must not take the headline down with it
             out[name] = {"error": "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0])}
     return out

@@ -1,6 +1,6 @@
 // launch_small.hip -- host side of the small-net path: the row-block kernel (middle4_kernel.h, with its run-time
 // instantiation, jit.h) and the tile-owner kernel (tile_step_kernel.h).
-#include "handle.h"
+#include "static_shapes.h"
 #include "jit.h"
 
 using namespace gnn;
@@ -10,26 +10,7 @@ namespace gnn {
 namespace host {
 
 // ---- middle4_kernel plan ----------------------------------------------------------------------
-// kernel table: [shape policy][activation][output kind][backward]
-// variant: 0 forward only, 1 forward + backward, 2 forward + backward with A_1 from the K slabs of tile_step_kernel
-template <class SH, int OUTK> const void *mid4_fn_sh(int act, int variant) {
-#define GNN_M4(A) (variant == 3 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true, false, true, true>) \
-                   : variant == 2 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true, false, true>)  \
-                   : variant == 1 ? reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, true>)             \
-                                  : reinterpret_cast<const void *>(&middle4_kernel<SH, A, OUTK, false>))
-    switch (act) {
-    case 0: return GNN_M4(0);
-    case 1: return GNN_M4(1);
-    case 2: return GNN_M4(2);
-    case 3: return GNN_M4(3);
-    default: return GNN_M4(4);
-    }
-#undef GNN_M4
-}
-// shapes with compile-time plans (BASELINE.json configs that take the fused path)
-using ShapeMnistA = StaticShape<784, 300, 100, 10>;
-using ShapeMnistB = StaticShape<784, 100, 50, 10>;
-
+// (the prebuilt instances and their tables: static_shapes.h; the GeneralNeuralNet ones live in launch_small_gnn.hip)
 template <class SH> bool shape_matches(const gnn_mlp *h) {
     constexpr int n = (int)(sizeof(SH::kDims) / sizeof(int));
     if (h->L != n) return false;
@@ -37,12 +18,18 @@ template <class SH> bool shape_matches(const gnn_mlp *h) {
     return true;
 }
 
+// 0 / 1: the net has one of the two prebuilt shapes (either output kind); -1: it does not, or GNN_MLP_STATIC=0
+int static_shape_of(const gnn_mlp *h) {
+    if (h->env_static_off) return -1;
+    if (shape_matches<ShapeMnistA>(h)) return 0;
+    if (shape_matches<ShapeMnistB>(h)) return 1;
+    return -1;
+}
+
 const void *mid4_function(const gnn_mlp *h, int variant) {
-    const bool allow_static = !h->env_static_off;
-    if (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE) {
-        if (shape_matches<ShapeMnistA>(h)) return mid4_fn_sh<ShapeMnistA, 0>(h->inner_act, variant);
-        if (shape_matches<ShapeMnistB>(h)) return mid4_fn_sh<ShapeMnistB, 0>(h->inner_act, variant);
-    }
+    const int which = static_shape_of(h);
+    if (which >= 0)
+        return h->out_kind == GNN_OUT_SOFTMAX_CE ? mid4_static_table<0>(which, h->inner_act, variant) : mid4_static_general(which, h->inner_act, variant);
     // runtime extents: layer count templated (3..6, else generic), activation read from the arguments
 #define GNN_M4RO(NL, OK) (variant == 3 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true, false, true, true>) \
                           : variant == 2 ? reinterpret_cast<const void *>(&middle4_kernel<RuntimeShape<NL>, -1, OK, true, false, true>) \
@@ -78,11 +65,7 @@ void plan_mid4(gnn_mlp *h) {
     }
     m.last_act = h->last_act;
     m.inner_act = h->inner_act;
-    {
-        const bool allow_static = !h->env_static_off;
-        h->specialization = (allow_static && h->out_kind == GNN_OUT_SOFTMAX_CE &&
-                             (shape_matches<ShapeMnistA>(h) || shape_matches<ShapeMnistB>(h))) ? 1 : 0;
-    }
+    h->specialization = static_shape_of(h) >= 0 ? 1 : 0;
     for (int bwd = (bf16 ? 2 : 0); bwd < 3; bwd++) {
         h->mid4_fn[bwd] = mid4_function(h, (bf16 && bwd == 2) ? 3 : bwd);
         if (hipFuncSetAttribute(h->mid4_fn[bwd], hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -95,17 +78,6 @@ void plan_mid4(gnn_mlp *h) {
 }
 
 // ---- rowblock_kernel plan -----------------------------------------------------------------------
-using RbMnistA = RbStaticShape<784, 300, 100, 10>;
-using RbMnistB = RbStaticShape<784, 100, 50, 10>;
-template <class SH, bool BF> const void *rb_fn_static(int act) {
-    switch (act) {
-    case 0: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 0, 0, false, 0, BF>);
-    case 1: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 1, 0, false, 0, BF>);
-    case 2: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 2, 0, false, 0, BF>);
-    case 3: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 3, 0, false, 0, BF>);
-    default: return reinterpret_cast<const void *>(&rowblock_kernel<SH, 4, 0, false, 0, BF>);
-    }
-}
 template <int NL, bool BF> const void *rb_fn_runtime(int out_kind) {
     return out_kind == GNN_OUT_SOFTMAX_CE ? reinterpret_cast<const void *>(&rowblock_kernel<RbRuntimeShape<NL>, -1, 0, false, 0, BF>)
                                           : reinterpret_cast<const void *>(&rowblock_kernel<RbRuntimeShape<NL>, -1, 1, false, 0, BF>);
@@ -132,9 +104,11 @@ void plan_rowblock(gnn_mlp *h) {
     r.last_act = h->last_act;
     r.inner_act = h->inner_act;
     r.slabs = h->slabs; r.slab_rows = h->cap_rows;
-    const bool allow_static = !h->env_static_off && h->out_kind == GNN_OUT_SOFTMAX_CE;
-    if (allow_static && shape_matches<ShapeMnistA>(h)) { h->rb_fn = bf ? rb_fn_static<RbMnistA, true>(h->inner_act) : rb_fn_static<RbMnistA, false>(h->inner_act); h->rb_static = 1; }
-    else if (allow_static && shape_matches<ShapeMnistB>(h)) { h->rb_fn = bf ? rb_fn_static<RbMnistB, true>(h->inner_act) : rb_fn_static<RbMnistB, false>(h->inner_act); h->rb_static = 1; }
+    const int which = static_shape_of(h);
+    if (which >= 0) {
+        h->rb_fn = h->out_kind == GNN_OUT_SOFTMAX_CE ? rb_static_table<0>(which, h->inner_act, bf) : rb_static_general(which, h->inner_act, bf);
+        h->rb_static = 1;
+    }
     else if (bf) h->rb_fn = L == 3 ? rb_fn_runtime<3, true>(h->out_kind) : rb_fn_runtime<4, true>(h->out_kind);
     else {
         switch (L) {

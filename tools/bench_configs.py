@@ -33,9 +33,11 @@ PEAK_TF = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peak
 HBM_GBS = 8000.0
 
 
-def run(key, dtype, steps, graph=False, n_batches=8, timed_kernels=True):
+def run(key, dtype, steps, graph=False, n_batches=8, timed_kernels=True, general=None):
     """graph: the hipGraph-captured training step of gnn_mlp_train_range (GNN_MLP_GRAPH=1, read at create): one pass over
-    the resident batches captured once, replayed; `steps` should then be a multiple of 2 * n_batches."""
+    the resident batches captured once, replayed; `steps` should then be a multiple of 2 * n_batches.
+    general: (inner_act, last_act) -> the same shape as a GeneralNeuralNet (element-wise output + half-squared loss,
+    GNN:215-218, 236-239, 267-271) instead of SoftmaxCrossEntropyNeuralNet."""
     import torch
     dims, B, label = CONFIGS[key]
     rng = np.random.default_rng(0)
@@ -45,7 +47,12 @@ def run(key, dtype, steps, graph=False, n_batches=8, timed_kernels=True):
     old = os.environ.get("GNN_MLP_GRAPH")
     os.environ["GNN_MLP_GRAPH"] = "1" if graph else "0"   # (read once, at create)
     try:
-        net = gnn_amd.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn_amd.DTYPE_BF16 if dtype == "bf16" else gnn_amd.DTYPE_F32, max_batch=B)
+        dt_enum = gnn_amd.DTYPE_BF16 if dtype == "bf16" else gnn_amd.DTYPE_F32
+        if general is not None:
+            net = gnn_amd.GeneralNeuralNet(dims, inner_act=general[0], last_act=general[1], dtype=dt_enum, max_batch=B)
+            label = label + ", GeneralNeuralNet %s/%s + half-squared loss" % tuple(general)
+        else:
+            net = gnn_amd.SoftmaxCrossEntropyNeuralNet(dims, dtype=dt_enum, max_batch=B)
     finally:
         if old is None:
             del os.environ["GNN_MLP_GRAPH"]
@@ -100,7 +107,8 @@ def run(key, dtype, steps, graph=False, n_batches=8, timed_kernels=True):
             "mfma_frac": round(f / (grad_us * 1e-6) / 1e12 / PEAK_TF[dtype], 4)}
     line = {"metric": "training samples/sec, %s" % label, "value": round(B / dt, 1), "unit": "samples/s", "n_gpus": 1,
             "steps": steps, "ms_per_step": round(dt * 1e3, 5), "us_per_step_events": round(dt_ev * 1e6, 2), "dtype": dtype, "data": "synthetic",
-            "config": {"workload": label, "dims": dims, "batch": B, "step_launches": net.step_launches, "hipgraph": bool(graph)},
+            "config": {"workload": label, "dims": dims, "batch": B, "step_launches": net.step_launches, "hipgraph": bool(graph),
+                       "batches_resident": nb, "specialization": net.specialization, "rowblock_state": net.rowblock_state},
             "roofline": {"bound": bound, "kernel": "whole gradientStep (forward + backward GEMM chain + update)",
                          "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
                          "flop_per_step": flop, "algorithmic_bytes_per_step": nbytes,
@@ -125,9 +133,9 @@ def main():
     for key in which:
         for dtype in dtypes:
             n = steps or (200 if key in ("4", "5") else 2000)
-            print(json.dumps(run(key, dtype, n)), flush=True)
+            print(json.dumps(run(key, dtype, n, n_batches=16 if key == "5" else 8)), flush=True)
             if graph and key == "5":   # configs[4] names the hipGraph-captured step: both forms, side by side
-                print(json.dumps(run(key, dtype, n - n % 16, graph=True)), flush=True)
+                print(json.dumps(run(key, dtype, n - n % 32, graph=True, n_batches=16)), flush=True)
 
 
 if __name__ == "__main__":
