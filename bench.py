@@ -45,6 +45,13 @@ if ROOT not in sys.path:
 DIMS = [784, 300, 100, 10]
 BATCH = 128
 N_BATCHES = 64                 # synthetic batches resident in HBM per rank
+# --workload: the headline is configs[1]; configs[4] (BASELINE: "1 and 8 GPUs") is the second data-parallel workload, run as a
+# variant of the N > 1 record.  (dims, rows per GPU, resident batches, factor on the Random(1) weights -- 0.05 keeps the softmax
+# of a 1024-wide net unsaturated, as tools/bench_configs.py does --, label)
+WORKLOADS = {
+    "configs1": ([784, 300, 100, 10], 128, 64, 1.0, "784-300-100-10 SoftmaxCrossEntropyNeuralNet gradientStep"),
+    "configs4": ([784, 1024, 1024, 1024, 10], 256, 16, 0.05, "784-1024-1024-1024-10 SoftmaxCrossEntropyNeuralNet gradientStep"),
+}
 STEP, MOMENTUM = 0.0125, 0.9   # MT:227-229
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF figure is 2:1 sparse)
@@ -80,6 +87,13 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--inject-capture-failure", action="store_true",
                     help="test hook: a non-capturable call inside the capture, so that the capture really fails")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="configs1",
+                    help="configs1 = the headline (784-300-100-10, 128 rows per GPU); configs4 = 784-1024-1024-1024-10, 256 rows per GPU")
+    ap.add_argument("--no-dp-variants", action="store_true",
+                    help="N > 1: only the headline (one process per GPU, RCCL); by default the same invocation also measures the "
+                         "in-library reducers, bf16 configs[2], configs[4] and one GPU alone, each in fresh child processes")
+    ap.add_argument("--variant-timeout", type=float, default=240.0, help="seconds one dp variant may take before it is ended")
+    ap.add_argument("--variant-child", action="store_true", help="(internal) this process measures ONE variant: no further children")
     args = ap.parse_args(argv)
     if args.no_graph:
         args.dp_mode = "eager"
@@ -113,25 +127,75 @@ def child_argv(argv, dp_mode):
     return out + ["--dp-mode", dp_mode]
 
 
-def run_group(argv, world, dp_mode, inject):
-    """Starts `world` fresh ranks of this script; returns (worst exit code, rank 0's stdout)."""
+def clean_env():
+    """The environment of a child that is NOT a rank of the group this process belongs to: nothing of an outer launcher's
+    rendezvous (torch.distributed.run exports RANK / WORLD_SIZE / MASTER_* / TORCHELASTIC_*; with TORCHELASTIC_USE_AGENT_STORE
+    set, rank 0 of a fresh group would wait for the outer agent's store instead of hosting its own)."""
+    drop = {"RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+            "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "GNN_BENCH_LAUNCHER"}
+    return {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
+
+
+def child_setup(new_session):
+    """preexec of every child: it dies with this process (PR_SET_PDEATHSIG: a launcher the driver ends at its time limit must not
+    leave ranks on the GPUs); a child that may have to be ended at a time limit also leads a session of its own."""
+    def setup():
+        import ctypes
+        import signal
+        if new_session:
+            os.setsid()
+        try:
+            ctypes.CDLL(None).prctl(1, int(signal.SIGKILL))   # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+    return setup
+
+
+def end_process_group(p):
+    """Ends child `p` -- and, when it was started as the leader of its own session, exactly that process group."""
+    import signal
+    try:
+        if os.getpgid(p.pid) == p.pid:
+            os.killpg(p.pid, signal.SIGKILL)
+    except (ProcessLookupError, PermissionError):
+        pass
+    try:
+        p.kill()
+    except Exception:
+        pass
+
+
+def run_group(argv, world, dp_mode, inject, timeout=None, stderr_to=None):
+    """Starts `world` fresh ranks of this script; returns (worst exit code, rank 0's stdout).  timeout: seconds after which
+    every rank is ended and 124 returned; stderr_to: a file the ranks' stderr goes to instead of this process's."""
     port = free_port()
     cmd = [sys.executable, os.path.abspath(__file__)] + child_argv(argv, dp_mode)
     if inject:
         cmd.append("--inject-capture-failure")
     procs = []
+    err = stderr_to if stderr_to is not None else sys.stderr
+    base = clean_env()
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GNN_BENCH_LAUNCHER="1")
-        procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else sys.stderr,
-                                      stderr=sys.stderr, text=(r == 0)))
+        procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else err,
+                                      stderr=err, text=(r == 0), preexec_fn=child_setup(timeout is not None)))
     # rank 0's stdout is one short line: reading it at the end cannot fill the pipe
     deadline_after_failure = None
+    t_end = None if timeout is None else time.time() + timeout
+    timed_out = False
     ended_here = set()
     while True:
         codes = [p.poll() for p in procs]
         if all(c is not None for c in codes):
             break
+        if t_end is not None and time.time() > t_end:
+            timed_out = True
+            for i, p in enumerate(procs):
+                if p.poll() is None:
+                    end_process_group(p)      # exact process groups of the children started above
+                    ended_here.add(i)
+            t_end = None
         if any(c not in (None, 0) for c in codes):
             # a rank died: its peers would wait in a collective for ever; give them a moment, then end them
             if deadline_after_failure is None:
@@ -139,11 +203,13 @@ def run_group(argv, world, dp_mode, inject):
             elif time.time() > deadline_after_failure:
                 for i, p in enumerate(procs):
                     if p.poll() is None:
-                        p.kill()          # exact PIDs of the children started above
+                        end_process_group(p)
                         ended_here.add(i)
         time.sleep(0.05)
     out0 = procs[0].stdout.read() if procs[0].stdout else ""
     codes = [p.returncode for p in procs]
+    if timed_out:
+        return 124, out0
     if any(c == EXIT_CAPTURE_FAILED for c in codes):
         return EXIT_CAPTURE_FAILED, out0
     worst = 0
@@ -153,6 +219,98 @@ def run_group(argv, world, dp_mode, inject):
             if i not in ended_here:
                 break
     return worst, out0
+
+
+def run_single(argv, timeout, stderr_to):
+    """ONE fresh child of this script that is not a rank of anything: (exit code, stdout); 124 when it was ended at `timeout`."""
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=clean_env(), cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=stderr_to, text=True, preexec_fn=child_setup(True))
+    try:
+        out, _ = p.communicate(timeout=timeout)
+        rc = p.returncode
+        return (rc if rc >= 0 else 128 - rc), out
+    except subprocess.TimeoutExpired:
+        end_process_group(p)
+        try:
+            out, _ = p.communicate(timeout=10)
+        except Exception:
+            out = ""
+        return 124, out
+
+
+# ---- the rest of the N > 1 record: every other data-parallel form, each in fresh child processes ---------------------------
+def dp_variant_specs(args):
+    """(name, "single" | "group", argv) of every variant measured beside the headline at N > 1.  `single` = one process (the
+    in-library forms own all N devices; `one GPU alone` is the same workload at N = 1); `group` = N ranks, one per GPU."""
+    n, K, W = args.gpus, args.steps, args.warmup
+    tail = ["--no-cpu-baseline", "--no-other-configs", "--no-dp-variants", "--variant-child"]
+    if args.share_gpu:
+        tail.append("--share-gpu")
+    ranks = ["--gpus", str(n), "--steps", str(K), "--warmup", str(W), "--backend", args.backend] + tail
+    lib = ["--gpus", str(n), "--steps", str(K), "--warmup", str(W), "--dp-impl", "library"] + tail
+    k4, w4 = min(K, 640), min(W, 64)
+    return [
+        ("one GPU alone (configs[1] f32, N = 1, same invocation)", "single",
+         ["--gpus", "1", "--steps", str(K), "--warmup", str(W)] + [t for t in tail if t != "--share-gpu"]),
+        ("library rccl f32 (one process over N devices, ncclAllReduce inside the library)", "single", lib + ["--dp-reducer", "rccl"]),
+        ("library direct f32 (peer-memory reduction fused into the tile kernel)", "single", lib + ["--dp-reducer", "direct"]),
+        ("library direct_rs f32 (peer-memory reduce-scatter, gather while updating)", "single", lib + ["--dp-reducer", "direct_rs"]),
+        ("ranks bf16 (BASELINE configs[2]: bf16 operands, global batch 128 N, RCCL all-reduce)", "group", ranks + ["--dtype", "bf16"]),
+        ("library direct bf16 (configs[2]'s arithmetic, one process over N devices)", "single", lib + ["--dp-reducer", "direct", "--dtype", "bf16"]),
+        ("ranks configs[4] f32 (784-1024-1024-1024-10, 256 rows per GPU, RCCL all-reduce of 11.6 MB)", "group",
+         ["--gpus", str(n), "--steps", str(k4), "--warmup", str(w4), "--backend", args.backend, "--workload", "configs4"] + tail),
+    ]
+
+
+def summarize_variant(line, wall_s):
+    c, r = line.get("config") or {}, line.get("roofline")
+    out = {k: line.get(k) for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype")}
+    out["config"] = {k: c[k] for k in ("workload", "global_batch", "parallelism", "dp_impl", "backend", "world_size", "dp_mode",
+                                       "dp_replicas_identical", "devices_shared") if k in c}
+    out["roofline"] = None if not r else {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us",
+                                                                "traffic", "share_of_step")}
+    out["child_wall_s"] = round(wall_s, 1)
+    return out
+
+
+def collect_variants(args):
+    """Runs every variant of dp_variant_specs in FRESH child processes, one after the other, from a process that never touches the
+    GPU.  A variant that fails or runs into --variant-timeout becomes {"error": ...} carrying the tail of its stderr; nothing a
+    variant does can take the headline down."""
+    import tempfile
+    out = {}
+    for name, kind, argv in dp_variant_specs(args):
+        t0 = time.time()
+        with tempfile.TemporaryFile(mode="w+") as errf:
+            try:
+                if kind == "group":
+                    rc, text = run_group(argv, args.gpus, "eager", False, timeout=args.variant_timeout, stderr_to=errf)
+                else:
+                    rc, text = run_single(argv, args.variant_timeout, errf)
+                lines = [l for l in (text or "").splitlines() if l.strip().startswith("{")]
+                if rc == 0 and len(lines) == 1:
+                    out[name] = summarize_variant(json.loads(lines[0]), time.time() - t0)
+                    continue
+                errf.seek(0)
+                tail = [l for l in errf.read().splitlines() if l.strip()][-6:]
+                what = ("ended at the %.0f s limit" % args.variant_timeout) if rc == 124 else "exit code %d" % rc
+                out[name] = {"error": what, "stderr_tail": [l[-300:] for l in tail], "child_wall_s": round(time.time() - t0, 1)}
+            except Exception as e:   # (a variant must not take the headline down)
+                out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        print("bench.py: dp variant '%s': %s" % (name, "ok" if "error" not in out[name] else out[name]["error"]), file=sys.stderr)
+    return out
+
+
+def merge_variants(headline_text, args):
+    """The headline's line with `dp_variants`, `single_gpu_value` (the same workload on ONE GPU, measured in this invocation) added."""
+    line = json.loads(headline_text)
+    variants = collect_variants(args)
+    single = next((v for k, v in variants.items() if k.startswith("one GPU alone")), None)
+    line["dp_variants"] = variants
+    line["single_gpu_value"] = single.get("value") if single and "error" not in single else None
+    line["dp_variants_note"] = ("each variant ran in its own fresh child process(es) after the headline; `value` above is the "
+                                "one-process-per-GPU RCCL form; scaling efficiency is left to the reader of the per-N values")
+    return json.dumps(line)
 
 
 def launch(args, argv):
@@ -171,7 +329,10 @@ def launch(args, argv):
             if len(lines) != 1:
                 print("bench.py launcher: rank 0 printed %d lines instead of one" % len(lines), file=sys.stderr)
                 return 1
-            print(lines[0], flush=True)
+            text = lines[0]
+            if args.gpus > 1 and not args.no_dp_variants and not args.variant_child:
+                text = merge_variants(text, args)
+            print(text, flush=True)
             return 0
         if i + 1 == len(modes):
             break
@@ -244,13 +405,34 @@ def other_configs():
     return out
 
 
-def synthetic(n, seed):
+def synthetic(n, seed, dims=None):
     """X ~ U[0,1) 784-dim, uniform one-hot labels; generated here, never shipped."""
     import numpy as np
+    dims = dims or DIMS
     rng = np.random.default_rng(seed)
-    X = rng.random((n, DIMS[0]))
-    Y = np.eye(DIMS[-1])[rng.integers(0, DIMS[-1], n)]
+    X = rng.random((n, dims[0]))
+    Y = np.eye(dims[-1])[rng.integers(0, dims[-1], n)]
     return X, Y
+
+
+def whole_step_roofline(dims, B, bf16, step_us):
+    """`roofline` quoted on the WHOLE step (the per-layer GEMM path of the wide configs: a chain of 3 (L - 1) GEMMs that all run at
+    the same roof) with SURVEY 8d's accounting: FLOP = (6P - 2 d0 d1) B; bytes = weights (P forward + (P - d0 d1) backward + P
+    gradient + 5P update) + activations B (d0 + 4 sum_{l>=1} d_l); bound = MFMA when the arithmetic intensity is above the ridge."""
+    P = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1))
+    flop = (6 * P - 2 * dims[0] * dims[1]) * B
+    eo = 2 if bf16 else 4
+    nbytes = eo * (2 * P - dims[0] * dims[1]) + 4 * 6 * P + eo * B * (dims[0] + 4 * sum(dims[1:]))
+    peak_tf = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+    tf, gbs = flop / (step_us * 1e-6) / 1e12, nbytes / (step_us * 1e-6) / 1e9
+    ridge, ai = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9), flop / nbytes
+    bound = "mfma" if ai >= ridge else "hbm"
+    ach, peak, unit = (tf, peak_tf, "TFLOP/s") if bound == "mfma" else (gbs, HBM_PEAK_GBS, "GB/s")
+    return {"bound": bound, "kernel": "whole gradientStep (forward + backward GEMM chain + exchange + update)", "achieved": round(ach, 2),
+            "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None, "avg_launch_us": round(step_us, 3), "launches": 1,
+            "flop_per_step": flop, "algorithmic_bytes_per_step": nbytes, "arithmetic_intensity_flop_per_byte": round(ai, 1),
+            "ridge_flop_per_byte": round(ridge, 1), "mfma_frac": round(tf / peak_tf, 4), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+            "share_of_step": 1.0, "other": {}}
 
 
 def cpu_baseline(seconds=12.0):
@@ -271,6 +453,112 @@ def cpu_baseline(seconds=12.0):
     return {"value": round(steps * BATCH / dt, 1), "unit": "samples/s", "cores": 1, "kind": "port",
             "sample": "%d gradientSteps of batch %d on 784-300-100-10 (fp64, per-sample loop order of "
                       "SCE:297-346; C restatement, not a JVM run)" % (steps, BATCH)}
+
+
+def kernel_roofline(timing_read, DIMS, BATCH, bf16, is_dp, two_launch, step_us, nt):
+    """The `roofline` object of the line from the per-kernel-class mean durations of the timed pass (the dispatches' own begin / end
+    timestamps, gnn_mlp_timing_read): quoted on the kernel with the largest share of the step.  is_dp: the gradient kernel stores G
+    and the update runs after the exchange; two_launch: row-block kernel + tile-owner kernel (csrc/tile_step_kernel.h)."""
+    roofline = None
+    fwd_us, fwd_n = timing_read(0)
+    grad_us, grad_n = timing_read(1)
+    mid_us, mid_n = timing_read(3)
+    upd_us, upd_n = timing_read(4)
+    P_all = sum(DIMS[l] * DIMS[l + 1] for l in range(len(DIMS) - 1))
+    P_mid = P_all - DIMS[0] * DIMS[1]
+    eo = 2 if bf16 else 4  # bytes per GEMM operand element
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+    # algorithmic work per launch (SURVEY 8d accounting; DESIGN.md section 5), f32 masters throughout:
+    #   fwd_first : 2*B*d0*d1 FLOP; reads A_0 (B*d0) + W_0 (d0*d1), writes A_1 (B*d1)
+    #   middle    : 2*B*2*(P - d0 d1) FLOP; reads W_1.. once per use (fwd + bwd), A_1, Y; writes A_2.., delta_1..
+    #   grad      : 2*B*P FLOP; reads A_l, delta_{l+1} for every layer and W, V (2P f32); writes W, V (2P f32)
+    #   (data-parallel path: the same kernel stores G instead -- P written, W and V untouched;
+    #    the update is sgd_momentum_kernel after the all-reduce)
+    f01 = 2.0 * BATCH * DIMS[0] * DIMS[1]     # one 784 x 300 product over the batch
+    if two_launch and not is_dp:
+        # the timed class "grad" is the tile-owner kernel: every layer's gradient + the update + the NEXT batch's
+        # first-layer product; "fwd" is the forward-only launch that opens a chain (once per training call)
+        names = {"fwd": "tile_step<forward only> (first layer of the chain's first batch, 128x784x300)",
+                 "mid": "row-block kernel (K-slab sum + f, layers 2.., softmax/CE, backward data)",
+                 "grad": "tile_step (G = A^T.delta all layers + momentum update + next batch's 128x784x300)"}
+        kernels = {
+            "fwd": (fwd_us, fwd_n, f01, eo * (BATCH * DIMS[0] + DIMS[0] * DIMS[1]) + 4 * BATCH * DIMS[1]),
+            "mid": (mid_us, mid_n, 2.0 * BATCH * 2 * P_mid,
+                    eo * 2 * P_mid + 4 * BATCH * DIMS[1] + eo * BATCH * 2 * sum(DIMS[1:]) + 4 * BATCH * 2 * DIMS[-1]),
+            "grad": (grad_us, grad_n, 2.0 * BATCH * P_all + f01,
+                     4 * 4 * P_all + (2 * P_all if bf16 else 0) + eo * BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:]))
+                     + eo * BATCH * DIMS[0] + 4 * BATCH * DIMS[1]),
+        }
+        gemm01 = ("grad", 2 * f01)            # both 784 x 300 products of a step run inside this kernel
+    else:
+        names = {"fwd": "first layer (128x784x300)", "mid": "middle(fwd L2.. + softmax + bwd-data)",
+                 "grad": "gradient kernel (all layers, 784x300xB + ...%s)" % (", stores G; update after the all-reduce" if is_dp else " + update")}
+        kernels = {
+            "fwd": (fwd_us, fwd_n, f01, eo * (BATCH * DIMS[0] + DIMS[0] * DIMS[1]) + eo * BATCH * DIMS[1]),
+            "mid": (mid_us, mid_n, 2.0 * BATCH * 2 * P_mid,
+                    eo * 2 * P_mid + eo * BATCH * (DIMS[1] + 2 * sum(DIMS[1:])) + 4 * BATCH * 2 * DIMS[-1]),
+            "grad": (grad_us, grad_n, 2.0 * BATCH * P_all,
+                     4 * (1 if is_dp else 4) * P_all + eo * BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:]))),
+        }
+        gemm01 = ("fwd", f01)
+        if is_dp and upd_n:
+            # data-parallel path: the update after the all-reduce -- by weight tiles with the next batch's first layer
+            # fused in (two-launch path, a next-batch hint given), else the flat momentum kernel
+            names["upd"] = "update after the all-reduce (+ next batch's 128x784x300 on the two-launch path)"
+            kernels["upd"] = (upd_us, upd_n, f01 if two_launch else 0.0,
+                              4 * 5 * P_all + (eo * BATCH * DIMS[0] + 4 * BATCH * DIMS[1] if two_launch else 0))
+            if two_launch:
+                gemm01 = ("upd", f01)
+    # kernel names in the PMC file: the two-launch path's kernels first, the three-launch ones as the fallback
+    pmc_key = {"fwd": ["tile_step_kernel<0, 0, true", "fwd_first"], "mid": ["rowblock", "middle4"],
+               "grad": ["tile_step_kernel<1, 2, true", "grad_update"], "upd": ["tile_step_kernel<2, 2, true", "sgd_momentum"]}
+    kernels = {k: v for k, v in kernels.items() if v[1] > 0 and v[0] > 0}
+    whole_flop = (6 * P_all - 2 * DIMS[0] * DIMS[1]) * BATCH
+    whole_bytes = 4 * (8 * P_all - DIMS[0] * DIMS[1] + BATCH * (DIMS[0] + 4 * sum(DIMS[1:])))
+
+    def entry(k):
+        us, n, flop, nbytes = kernels[k]
+        return {"name": names[k], "avg_us": round(us, 3), "launches": n, "flop": flop, "algorithmic_bytes": nbytes,
+                "tflops": round(flop / (us * 1e-6) / 1e12, 3), "gbs": round(nbytes / (us * 1e-6) / 1e9, 1),
+                "mfma_frac": round(flop / (us * 1e-6) / 1e12 / mfma_peak, 4),
+                "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "share_of_step": round(us * n / (step_us * nt), 3),
+                "mfma_util_counter": None if is_dp or bf16 else next((v for v in map(mfma_counter, pmc_key[k]) if v is not None), None),
+                "traffic": None if is_dp or bf16 else next((v for v in map(pmc_traffic, pmc_key[k]) if v is not None), None)}
+    if kernels:
+        # roofline kernel = the one with the largest share of the step's time.  Which roof: its
+        # arithmetic intensity against the ridge of this dtype (peak FLOP/s / 8 TB/s).
+        dom = max(kernels, key=lambda k: kernels[k][0] * kernels[k][1])   # total time in the timed pass = avg x launches
+        e = entry(dom)
+        ai = e["flop"] / e["algorithmic_bytes"]
+        ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if ai >= ridge:
+            bound, ach, peak, unit = "mfma", e["tflops"], mfma_peak, "TFLOP/s"
+        else:
+            bound, ach, peak, unit = "hbm", e["gbs"], HBM_PEAK_GBS, "GB/s"
+        return {"bound": bound, "kernel": e["name"], "achieved": ach, "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "traffic": e["traffic"],
+                    "traffic_source": PMC_FILE if e["traffic"] is not None else None,
+                    "avg_launch_us": e["avg_us"], "launches": e["launches"],
+                    # the MFMA pipe's busy share by COUNTER (rocprofv3 pass in profiles/, same command), beside FLOP/time/peak
+                    "mfma_util_counter": None if is_dp or bf16 else next((v for v in map(mfma_counter, pmc_key[dom]) if v is not None), None),
+                    "mfma_util_counter_source": MFMA_FILE,
+                    "algorithmic_bytes_per_launch": e["algorithmic_bytes"], "flop_per_launch": e["flop"],
+                    "arithmetic_intensity_flop_per_byte": round(ai, 2), "ridge_flop_per_byte": round(ridge, 1),
+                    "share_of_step": e["share_of_step"],
+                    "limiter": "launch + memory latency and instruction issue, not bandwidth or MFMA rate: the launch moves "
+                               "<1 MB and <0.1 GFLOP (DESIGN.md 3.3)",
+                    # the north-star GEMM: FLOPs of the 784x300 product(s) / the time of the kernel they run in / MFMA peak
+                    "gemm_784x300_mfma_frac": (round(gemm01[1] / (kernels[gemm01[0]][0] * 1e-6) / 1e12 / mfma_peak, 4)
+                                               if gemm01[0] in kernels else None),
+                    "gemm_784x300_kernel": names[gemm01[0]] if gemm01[0] in kernels else None,
+                    # SURVEY 8d, whole step: 6P - 2 d0 d1 FLOP per sample; bytes = weights (P + (P - d0 d1) + P + 5P)
+                    # + activations B (d0 + 4 sum_{l>=1} d_l), 4 B each
+                    "whole_step": {"flop": whole_flop, "algorithmic_bytes": whole_bytes, "us": round(step_us, 3),
+                                   "mfma_frac": round(whole_flop / (step_us * 1e-6) / 1e12 / mfma_peak, 4),
+                                   "hbm_frac": round(whole_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "other": {names[k]: entry(k) for k in kernels if k != dom}}
+    return roofline
 
 
 def library_worker(args):
@@ -302,6 +590,17 @@ def library_worker(args):
     net.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # per-kernel roofline as on the rank path: the dispatches' own timestamps on replica 0 (every replica runs the same launches
+    # on its 128 rows), over a further pass of the same loop
+    nt = min(K, 256)
+    r0 = net.replicas[0]
+    r0.timing_enable(True)
+    net.train_range(((W + K) % N_BATCHES) * Bg, Bg, nt, STEP, MOMENTUM)
+    net.synchronize()
+    roofline = kernel_roofline(r0.timing_read, DIMS, BATCH, bf16, True, r0.step_launches == 2, dt / K * 1e6, nt)
+    r0.timing_enable(False)
+    identical = net.replicas_identical()
+    cpu = None if args.no_cpu_baseline else cpu_baseline()
     line = {
         "metric": "training samples/sec, 784-300-100-10 MLP batch 128",
         "value": round(K * Bg / dt, 1), "unit": "samples/s", "n_gpus": n, "steps": K, "warmup": W,
@@ -311,18 +610,26 @@ def library_worker(args):
                                % (("bf16 GEMM operands / f32 accumulate and masters", 2) if bf16 else ("fp32", 1)),
                    "global_batch": Bg, "parallelism": "dp%d" % n, "dp_impl": "library: one process, one handle over %d devices" % n,
                    "backend": args.dp_reducer, "world_size": n, "devices_shared": bool(args.share_gpu),
-                   "dp_replicas_identical": net.replicas_identical(), "step": STEP, "momentum": MOMENTUM, "inner_activation": "leaky_relu"},
-        "roofline": None, "cpu_baseline": None,
+                   "dp_replicas_identical": identical, "step": STEP, "momentum": MOMENTUM, "inner_activation": "leaky_relu"},
+        "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
 
 
 def supervise_own_rank(args, argv):
     """This process was started as ONE rank by someone else (torch.distributed.run), or is the single
-    process of `--dp-path`.  It stays off the GPU and runs the rank as a child: the graph attempt
+    process of `--dp-path`.  It stays off the GPU and runs the rank as a child: on one rank the graph attempt
     first, and if that fails a fresh child in eager mode on the next rendezvous port (every rank's
-    supervisor takes the same decision from the same exit code)."""
-    modes = [args.dp_mode] if args.dp_mode != "auto" else ["graph", "eager"]
+    supervisor takes the same decision from the same exit code); on more than one rank eager steps (see launch()).
+    Rank 0's supervisor then measures the other data-parallel forms (collect_variants) once the ranks are gone,
+    and prints the merged line."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dp_mode != "auto":
+        modes = [args.dp_mode]
+    elif world > 1:
+        modes = ["graph", "eager"] if args.inject_capture_failure else ["eager"]
+    else:
+        modes = ["graph", "eager"]
     rc = 1
     for i, mode in enumerate(modes):
         env = dict(os.environ, GNN_BENCH_LAUNCHER="1")
@@ -335,8 +642,15 @@ def supervise_own_rank(args, argv):
         p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
         rc = p.returncode
         if rc == 0:
-            if p.stdout.strip():
-                print(p.stdout.strip(), flush=True)
+            text = p.stdout.strip()
+            if text and world > 1 and os.environ.get("RANK", "0") == "0" and not args.no_dp_variants and not args.variant_child:
+                time.sleep(2.0)   # (the other ranks' children left the barrier with this one's: let them release their devices)
+                try:
+                    text = merge_variants(text.splitlines()[-1], args)
+                except Exception as e:
+                    print("bench.py rank supervisor: dp variants failed (%s: %s); headline only" % (type(e).__name__, e), file=sys.stderr)
+            if text:
+                print(text, flush=True)
             return 0
         if i + 1 < len(modes):
             print("bench.py rank supervisor: the hipGraph attempt failed (%s); fresh child in eager mode"
@@ -388,9 +702,13 @@ def worker(args, argv):
 
     K, W = args.steps, args.warmup
     bf16 = args.dtype == "bf16"
-    X, Y = synthetic(BATCH * N_BATCHES, 1000 + rank)  # each rank owns its row shard of the global batch
+    DIMS, BATCH, N_BATCHES, w_scale, wl_label = WORKLOADS[args.workload]   # (the headline's constants unless --workload says otherwise)
+    headline_shape = args.workload == "configs1"
+    X, Y = synthetic(BATCH * N_BATCHES, 1000 + rank, DIMS)  # each rank owns its row shard of the global batch
     net = gnn_amd.SoftmaxCrossEntropyNeuralNet(DIMS, device=local_rank, max_batch=BATCH,
                                                dtype=gnn_amd.DTYPE_BF16 if bf16 else gnn_amd.DTYPE_F32)
+    if w_scale != 1.0:
+        net.set_weights(net.get_weights() * w_scale)   # (the same on every rank: Random(1) draws, one factor)
     net.upload_dataset(X, Y)
 
     def barrier():
@@ -488,109 +806,12 @@ def worker(args, argv):
     run(W + K if dist is None else K, nt, eager=True)
     barrier()
     if rank == 0:
-        fwd_us, fwd_n = net.timing_read(0)
-        grad_us, grad_n = net.timing_read(1)
-        mid_us, mid_n = net.timing_read(3)
-        upd_us, upd_n = net.timing_read(4)
-        net.timing_enable(False)
-        P_all = sum(DIMS[l] * DIMS[l + 1] for l in range(len(DIMS) - 1))
-        P_mid = P_all - DIMS[0] * DIMS[1]
-        eo = 2 if bf16 else 4  # bytes per GEMM operand element
-        mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
-        # algorithmic work per launch (SURVEY 8d accounting), f32 masters throughout:
-        #   fwd_first : 2*B*d0*d1 FLOP; reads A_0 (B*d0) + W_0 (d0*d1), writes A_1 (B*d1)
-        #   middle    : 2*B*2*(P - d0 d1) FLOP; reads W_1.. once per use (fwd + bwd), A_1, Y; writes A_2.., delta_1..
-        #   grad      : 2*B*P FLOP; reads A_l, delta_{l+1} for every layer and W, V (2P f32); writes W, V (2P f32)
-        #   (data-parallel path: the same kernel stores G instead -- P written, W and V untouched;
-        #    the update is sgd_momentum_kernel after the all-reduce)
-        is_dp = dist is not None
-        two_launch = net.step_launches == 2      # tile-owner kernel + row-block kernel (csrc/tile_step_kernel.h)
-        f01 = 2.0 * BATCH * DIMS[0] * DIMS[1]     # one 784 x 300 product over the batch
-        if two_launch and not is_dp:
-            # the timed class "grad" is the tile-owner kernel: every layer's gradient + the update + the NEXT batch's
-            # first-layer product; "fwd" is the forward-only launch that opens a chain (once per training call)
-            names = {"fwd": "tile_step<forward only> (first layer of the chain's first batch, 128x784x300)",
-                     "mid": "row-block kernel (K-slab sum + f, layers 2.., softmax/CE, backward data)",
-                     "grad": "tile_step (G = A^T.delta all layers + momentum update + next batch's 128x784x300)"}
-            kernels = {
-                "fwd": (fwd_us, fwd_n, f01, eo * (BATCH * DIMS[0] + DIMS[0] * DIMS[1]) + 4 * BATCH * DIMS[1]),
-                "mid": (mid_us, mid_n, 2.0 * BATCH * 2 * P_mid,
-                        eo * 2 * P_mid + 4 * BATCH * DIMS[1] + eo * BATCH * 2 * sum(DIMS[1:]) + 4 * BATCH * 2 * DIMS[-1]),
-                "grad": (grad_us, grad_n, 2.0 * BATCH * P_all + f01,
-                         4 * 4 * P_all + (2 * P_all if bf16 else 0) + eo * BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:]))
-                         + eo * BATCH * DIMS[0] + 4 * BATCH * DIMS[1]),
-            }
-            gemm01 = ("grad", 2 * f01)            # both 784 x 300 products of a step run inside this kernel
+        if headline_shape:
+            roofline = kernel_roofline(net.timing_read, DIMS, BATCH, bf16, dist is not None, net.step_launches == 2, dt / K * 1e6, nt)
         else:
-            names = {"fwd": "first layer (128x784x300)", "mid": "middle(fwd L2.. + softmax + bwd-data)",
-                     "grad": "gradient kernel (all layers, 784x300xB + ...%s)" % (", stores G; update after the all-reduce" if is_dp else " + update")}
-            kernels = {
-                "fwd": (fwd_us, fwd_n, f01, eo * (BATCH * DIMS[0] + DIMS[0] * DIMS[1]) + eo * BATCH * DIMS[1]),
-                "mid": (mid_us, mid_n, 2.0 * BATCH * 2 * P_mid,
-                        eo * 2 * P_mid + eo * BATCH * (DIMS[1] + 2 * sum(DIMS[1:])) + 4 * BATCH * 2 * DIMS[-1]),
-                "grad": (grad_us, grad_n, 2.0 * BATCH * P_all,
-                         4 * (1 if is_dp else 4) * P_all + eo * BATCH * (sum(DIMS[:-1]) + sum(DIMS[1:]))),
-            }
-            gemm01 = ("fwd", f01)
-            if is_dp and upd_n:
-                # data-parallel path: the update after the all-reduce -- by weight tiles with the next batch's first layer
-                # fused in (two-launch path, a next-batch hint given), else the flat momentum kernel
-                names["upd"] = "update after the all-reduce (+ next batch's 128x784x300 on the two-launch path)"
-                kernels["upd"] = (upd_us, upd_n, f01 if two_launch else 0.0,
-                                  4 * 5 * P_all + (eo * BATCH * DIMS[0] + 4 * BATCH * DIMS[1] if two_launch else 0))
-                if two_launch:
-                    gemm01 = ("upd", f01)
-        # kernel names in the PMC file: the two-launch path's kernels first, the three-launch ones as the fallback
-        pmc_key = {"fwd": ["tile_step_kernel<0, 0, true", "fwd_first"], "mid": ["rowblock", "middle4"],
-                   "grad": ["tile_step_kernel<1, 2, true", "grad_update"], "upd": ["tile_step_kernel<2, 2, true", "sgd_momentum"]}
-        kernels = {k: v for k, v in kernels.items() if v[1] > 0 and v[0] > 0}
-        step_us = dt / K * 1e6
-        whole_flop = (6 * P_all - 2 * DIMS[0] * DIMS[1]) * BATCH
-        whole_bytes = 4 * (8 * P_all - DIMS[0] * DIMS[1] + BATCH * (DIMS[0] + 4 * sum(DIMS[1:])))
-
-        def entry(k):
-            us, n, flop, nbytes = kernels[k]
-            return {"name": names[k], "avg_us": round(us, 3), "launches": n, "flop": flop, "algorithmic_bytes": nbytes,
-                    "tflops": round(flop / (us * 1e-6) / 1e12, 3), "gbs": round(nbytes / (us * 1e-6) / 1e9, 1),
-                    "mfma_frac": round(flop / (us * 1e-6) / 1e12 / mfma_peak, 4),
-                    "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                    "share_of_step": round(us * n / (step_us * nt), 3),
-                    "mfma_util_counter": None if is_dp or bf16 else next((v for v in map(mfma_counter, pmc_key[k]) if v is not None), None),
-                    "traffic": None if is_dp or bf16 else next((v for v in map(pmc_traffic, pmc_key[k]) if v is not None), None)}
-        if kernels:
-            # roofline kernel = the one with the largest share of the step's time.  Which roof: its
-            # arithmetic intensity against the ridge of this dtype (peak FLOP/s / 8 TB/s).
-            dom = max(kernels, key=lambda k: kernels[k][0] * kernels[k][1])   # total time in the timed pass = avg x launches
-            e = entry(dom)
-            ai = e["flop"] / e["algorithmic_bytes"]
-            ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
-            if ai >= ridge:
-                bound, ach, peak, unit = "mfma", e["tflops"], mfma_peak, "TFLOP/s"
-            else:
-                bound, ach, peak, unit = "hbm", e["gbs"], HBM_PEAK_GBS, "GB/s"
-            roofline = {"bound": bound, "kernel": e["name"], "achieved": ach, "peak": peak, "unit": unit,
-                        "frac": round(ach / peak, 4), "traffic": e["traffic"],
-                        "traffic_source": PMC_FILE if e["traffic"] is not None else None,
-                        "avg_launch_us": e["avg_us"], "launches": e["launches"],
-                        # the MFMA pipe's busy share by COUNTER (rocprofv3 pass in profiles/, same command), beside FLOP/time/peak
-                        "mfma_util_counter": None if is_dp or bf16 else next((v for v in map(mfma_counter, pmc_key[dom]) if v is not None), None),
-                        "mfma_util_counter_source": MFMA_FILE,
-                        "algorithmic_bytes_per_launch": e["algorithmic_bytes"], "flop_per_launch": e["flop"],
-                        "arithmetic_intensity_flop_per_byte": round(ai, 2), "ridge_flop_per_byte": round(ridge, 1),
-                        "share_of_step": e["share_of_step"],
-                        "limiter": "launch + memory latency and instruction issue, not bandwidth or MFMA rate: the launch moves "
-                                   "<1 MB and <0.1 GFLOP (DESIGN.md 3.3)",
-                        # the north-star GEMM: FLOPs of the 784x300 product(s) / the time of the kernel they run in / MFMA peak
-                        "gemm_784x300_mfma_frac": (round(gemm01[1] / (kernels[gemm01[0]][0] * 1e-6) / 1e12 / mfma_peak, 4)
-                                                   if gemm01[0] in kernels else None),
-                        "gemm_784x300_kernel": names[gemm01[0]] if gemm01[0] in kernels else None,
-                        # SURVEY 8d, whole step: 6P - 2 d0 d1 FLOP per sample; bytes = weights (P + (P - d0 d1) + P + 5P)
-                        # + activations B (d0 + 4 sum_{l>=1} d_l), 4 B each
-                        "whole_step": {"flop": whole_flop, "algorithmic_bytes": whole_bytes, "us": round(step_us, 3),
-                                       "mfma_frac": round(whole_flop / (step_us * 1e-6) / 1e12 / mfma_peak, 4),
-                                       "hbm_frac": round(whole_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
-                        "other": {names[k]: entry(k) for k in kernels if k != dom}}
-        if dist is None:
+            roofline = whole_step_roofline(DIMS, BATCH, bf16, dt / K * 1e6)
+        net.timing_enable(False)
+        if dist is None and headline_shape and not args.variant_child:
             # PCIe-inclusive rate of the literal NeuralNet.gradientStep(double[] rows) call shape: fp64 host
             # batch -> f32 in a pinned slot -> staging kernel reading it over PCIe -> step.  Reported beside `value`, never as `value`.
             nh = 200
@@ -607,7 +828,7 @@ def worker(args, argv):
                 cpu = cpu_baseline()
 
     others = None
-    if rank == 0 and dist is None and not args.no_other_configs:
+    if rank == 0 and dist is None and not args.no_other_configs and not args.variant_child:
         net.close()
         others = other_configs()
 
@@ -621,7 +842,8 @@ def worker(args, argv):
     if rank == 0:
         total = K * BATCH * world
         line = {
-            "metric": "training samples/sec, 784-300-100-10 MLP batch 128",
+            "metric": "training samples/sec, 784-300-100-10 MLP batch 128" if headline_shape else
+                      "training samples/sec, %s MLP batch %d" % ("-".join(map(str, DIMS)), BATCH),
             "value": round(total / dt, 1), "unit": "samples/s",
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 5),
@@ -629,10 +851,9 @@ def worker(args, argv):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "host_batch_samples_per_s": host_rate,
-            "config": {"workload": "784-300-100-10 SoftmaxCrossEntropyNeuralNet gradientStep, %s, batch 128 per GPU "
-                                   "(BASELINE configs[%d])" % ("bf16 GEMM operands / f32 accumulate and masters", 2) if bf16 else
-                                   "784-300-100-10 SoftmaxCrossEntropyNeuralNet gradientStep, fp32, batch 128 per GPU "
-                                   "(BASELINE configs[1])",
+            "config": {"workload": "%s, %s, batch %d per GPU (BASELINE configs[%d])"
+                                   % (wl_label, "bf16 GEMM operands / f32 accumulate and masters" if bf16 else "fp32", BATCH,
+                                      4 if not headline_shape else 2 if bf16 else 1),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                        "backend": None if dist is None else ("rccl" if args.backend == "nccl" else args.backend),
                        "world_size": None if dist is None else stepper.world,
@@ -661,8 +882,11 @@ def main():
     is_dp = args.gpus > 1 or args.dp_path
     first_mode = args.dp_mode if args.dp_mode != "auto" else (
         "graph" if (args.backend == "nccl" and args.gpus == 1) or args.inject_capture_failure else "eager")
-    if is_dp and first_mode == "graph" and os.environ.get("GNN_BENCH_LAUNCHER") != "1":
-        sys.exit(supervise_own_rank(args, argv))   # a graph attempt is never made in an unsupervised process
+    supervised = os.environ.get("GNN_BENCH_LAUNCHER") == "1"
+    # a graph attempt is never made in an unsupervised process; and a rank of a world > 1 that someone else started
+    # (torch.distributed.run) is supervised too, so that rank 0's supervisor can add the dp variants afterwards
+    if is_dp and not supervised and (first_mode == "graph" or (world_env is not None and args.gpus > 1 and not args.no_dp_variants)):
+        sys.exit(supervise_own_rank(args, argv))
     worker(args, argv)
 
 

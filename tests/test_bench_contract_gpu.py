@@ -75,13 +75,52 @@ def test_bench_two_ranks_self_launched():
     c = line["config"]
     assert c["backend"] == "gloo" and c["world_size"] == 2 and c["dp_mode"] == "eager"
     assert c["dp_replicas_identical"] is True and c["parallelism"] == "dp2"
+    check_dp_variants(line, 2)
+
+
+def check_dp_variants(line, n):
+    """The rest of the N > 1 record, measured by the same invocation in fresh children (rehearsed here with both replicas / ranks
+    on the one GPU, gloo carrying the ranks' all-reduce): every variant either a summary with value + roofline, or {"error": ..}.
+    The in-library RCCL form needs one DISTINCT device per replica, so on this box it is the variant that fails -- and shows that a
+    failing variant leaves the line intact."""
+    v = line["dp_variants"]
+    assert len(v) == 7
+    by = lambda frag: next(v[k] for k in v if frag in k)
+    assert "error" in by("library rccl") and any("distinct device" in l for l in by("library rccl")["stderr_tail"])
+    for frag, n_gpus, dtype in (("one GPU alone", 1, "f32"), ("library direct f32", n, "f32"), ("library direct_rs f32", n, "f32"),
+                                ("ranks bf16", n, "bf16"), ("library direct bf16", n, "bf16"), ("ranks configs[4]", n, "f32")):
+        e = by(frag)
+        assert "error" not in e, (frag, e)
+        assert e["value"] > 0 and e["n_gpus"] == n_gpus and e["dtype"] == dtype and e["roofline"] is not None, (frag, e)
+        assert e["roofline"]["bound"] in ("hbm", "mfma") and e["roofline"]["frac"] >= 0
+        if n_gpus > 1:
+            assert e["config"]["dp_replicas_identical"] is True, frag
+    assert by("ranks configs[4]")["config"]["global_batch"] == 256 * n and "784-1024-1024-1024-10" in by("ranks configs[4]")["config"]["workload"]
+    assert by("ranks bf16")["config"]["global_batch"] == 128 * n
+    assert line["single_gpu_value"] == by("one GPU alone")["value"]
+
+
+def test_bench_two_ranks_started_by_torch_distributed_run():
+    """The contract's call shape at N > 1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`.  Every rank the
+    launcher starts supervises a child (the rank proper); rank 0's supervisor adds the dp variants once the ranks are gone and
+    prints the ONE line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GNN_BENCH_LAUNCHER")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "128", "--warmup", "64",
+                          "--no-cpu-baseline", "--backend", "gloo", "--share-gpu"], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[:2000]
+    line = json.loads(lines[0])
+    check(line, n_gpus=2, shared_gpu=True)
+    check_dp_variants(line, 2)
 
 
 def test_bench_capture_failure_hands_over_to_fresh_eager_ranks():
     """A hipGraph capture that fails (here: a gloo collective, which cannot be captured, plus a
     call that is not permitted while capturing) leaves the capturing stream invalidated; the ranks
     must stop using the GPU and exit, and the eager run must come from FRESH processes."""
-    line, err = run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--inject-capture-failure", want_stderr=True)
+    line, err = run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--inject-capture-failure", "--no-dp-variants", want_stderr=True)
     check(line, n_gpus=2, shared_gpu=True)
     assert "hipGraph capture failed" in err and "starting fresh ranks in eager mode" in err
     assert line["config"]["dp_mode"] == "eager" and line["config"]["dp_replicas_identical"] is True
@@ -125,3 +164,6 @@ def test_bench_library_data_parallel_rehearsal(reducer):
     assert line["n_gpus"] == 4 and line["config"]["global_batch"] == 512 and line["config"]["world_size"] == 4
     assert line["config"]["dp_replicas_identical"] is True and line["config"]["backend"] == reducer
     assert abs(line["value"] - 512 * 128 / (line["ms_per_step"] * 1e-3 * 128)) <= 0.01 * line["value"]
+    r = line["roofline"]                      # as on the rank path: the kernel with the largest share of replica 0's step
+    assert r is not None and r["bound"] in ("hbm", "mfma") and r["peak"] > 0 and "kernel" in r and "other" in r
+    assert line["cpu_baseline"] is None      # --no-cpu-baseline; without the flag the library form reports it like the rank form

@@ -33,14 +33,14 @@ def test_launcher_relays_one_line_and_falls_back_to_fresh_eager_ranks(monkeypatc
         return 0, '{"n_gpus": %d}\n' % world
     monkeypatch.setattr(b, "run_group", fake_group)
     # the driver's call shape: eager ranks, ONE attempt (graph replay on more than one rank is opt-in)
-    args = b.parse_args(["--gpus", "4"])
-    assert b.launch(args, ["--gpus", "4"]) == 0
+    args = b.parse_args(["--gpus", "4", "--no-dp-variants"])
+    assert b.launch(args, ["--gpus", "4", "--no-dp-variants"]) == 0
     assert calls == [(4, "eager")]
     assert capsys.readouterr().out.strip() == '{"n_gpus": 4}'
     # the test hook: a graph attempt that fails, then fresh ranks in eager mode
     calls.clear()
-    args = b.parse_args(["--gpus", "4", "--inject-capture-failure"])
-    assert b.launch(args, ["--gpus", "4", "--inject-capture-failure"]) == 0
+    args = b.parse_args(["--gpus", "4", "--inject-capture-failure", "--no-dp-variants"])
+    assert b.launch(args, ["--gpus", "4", "--inject-capture-failure", "--no-dp-variants"]) == 0
     assert calls == [(4, "graph"), (4, "eager")]
     assert capsys.readouterr().out.strip() == '{"n_gpus": 4}'
     # an explicit mode is not second-guessed; any other failure is passed through
@@ -54,7 +54,7 @@ def test_launcher_relays_one_line_and_falls_back_to_fresh_eager_ranks(monkeypatc
 def test_launcher_process_never_imports_torch():
     code = ("import sys; sys.path.insert(0, %r); import bench\n"
             "bench.run_group = lambda *a: (0, '{\"ok\": 1}\\n')\n"
-            "sys.argv = ['bench.py', '--gpus', '8']\n"
+            "sys.argv = ['bench.py', '--gpus', '8', '--no-dp-variants']\n"
             "try:\n    bench.main()\nexcept SystemExit as e:\n    assert e.code == 0, e.code\n"
             "assert 'torch' not in sys.modules and 'gnn_amd' not in sys.modules\n") % ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
@@ -82,3 +82,61 @@ def test_run_group_real_children_worst_code_and_rank_env(tmp_path, monkeypatch):
     monkeypatch.setattr(b.time, "time", lambda _t=[0.0]: _t.__setitem__(0, _t[0] + 5.0) or _t[0])  # fast-forward the grace period
     rc, out = b.run_group(["--fail"], 3, "eager", False)
     assert rc == 7
+
+
+def test_dp_variants_are_merged_and_a_failing_one_does_not_take_the_headline_down(monkeypatch, capsys):
+    """`bench.py --gpus N` (N > 1): after the headline every other data-parallel form is measured in fresh children -- the
+    in-library reducers, bf16 configs[2], configs[4], one GPU alone -- and merged into the ONE line; a variant that fails or runs
+    into its time limit becomes {"error": ...} with the tail of its stderr."""
+    import json
+    b = _bench()
+    seen = []
+
+    def fake_group(argv, world, mode, inject, timeout=None, stderr_to=None):
+        seen.append(("group", tuple(argv)))
+        if "--variant-child" not in argv:
+            return 0, json.dumps({"value": 800.0, "n_gpus": world, "config": {"backend": "rccl"}}) + "\n"
+        if "--workload" in argv:                       # configs[4]: a rank dies
+            stderr_to.write("noise\nRuntimeError: rank 1 fell over\n"); stderr_to.flush()
+            return 3, ""
+        return 0, json.dumps({"value": 700.0, "unit": "samples/s", "n_gpus": world, "dtype": "bf16", "ms_per_step": 0.1,
+                              "config": {"backend": "rccl", "global_batch": 128 * world}, "roofline": {"bound": "hbm", "frac": 0.01}}) + "\n"
+
+    def fake_single(argv, timeout, stderr_to):
+        seen.append(("single", tuple(argv)))
+        if argv[:2] == ["--gpus", "1"]:
+            return 0, json.dumps({"value": 110.0, "n_gpus": 1, "config": {}, "roofline": None}) + "\n"
+        if "rccl" in argv:
+            return 124, ""                              # hangs: ended at the limit
+        return 0, "RCCL banner on stdout\n" + json.dumps({"value": 650.0, "n_gpus": 8, "config": {"backend": argv[argv.index("--dp-reducer") + 1]},
+                                                            "roofline": {"bound": "hbm", "frac": 0.02, "kernel": "k"}}) + "\n"
+    monkeypatch.setattr(b, "run_group", fake_group)
+    monkeypatch.setattr(b, "run_single", fake_single)
+    args = b.parse_args(["--gpus", "8", "--steps", "50", "--warmup", "10"])
+    assert b.launch(args, ["--gpus", "8", "--steps", "50", "--warmup", "10"]) == 0
+    line = json.loads(capsys.readouterr().out.strip())
+    assert line["value"] == 800.0 and line["n_gpus"] == 8           # the headline is the one-process-per-GPU RCCL form
+    v = line["dp_variants"]
+    assert len(v) == 7 and line["single_gpu_value"] == 110.0
+    names = list(v)
+    assert any("library rccl" in n for n in names) and any("direct_rs" in n for n in names) and any("configs[2]" in n for n in names)
+    rccl = next(v[n] for n in names if "library rccl" in n)
+    assert rccl["error"].startswith("ended at the") and "stderr_tail" in rccl
+    c4 = next(v[n] for n in names if "configs[4]" in n)
+    assert c4["error"] == "exit code 3" and c4["stderr_tail"][-1] == "RuntimeError: rank 1 fell over"
+    direct = next(v[n] for n in names if "library direct f32" in n)
+    assert direct["value"] == 650.0 and direct["roofline"]["frac"] == 0.02 and direct["config"]["backend"] == "direct"
+    # every variant child is told not to spawn anything itself, and keeps the caller's K / W
+    for kind, argv in seen[1:]:
+        assert "--variant-child" in argv and "--no-dp-variants" in argv and "--no-cpu-baseline" in argv
+    assert all("50" in argv for kind, argv in seen[1:] if "--workload" not in argv)
+
+
+def test_children_do_not_inherit_an_outer_launchers_rendezvous(monkeypatch):
+    b = _bench()
+    monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")
+    monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("MASTER_PORT", "1234")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e = b.clean_env()
+    assert not any(k.startswith("TORCHELASTIC_") for k in e) and "WORLD_SIZE" not in e and "RANK" not in e and "MASTER_PORT" not in e
+    assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
