@@ -402,6 +402,17 @@ def other_configs():
                          "hipgraph": graph, "batches_resident": nb, "bound": r["bound"], "mfma_frac": r["mfma_frac"], "hbm_frac": r["hbm_frac"]}
         except Exception as e:   # a config that fails must not take the headline down with it
             out[name] = {"error": "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0])}
+    # inference / evaluation throughput: testOnTrainingData (MT:181-197) over 60 000 resident rows as ONE call
+    # (gnn_mlp_count_hits_range), on a handle sized like a training handle (blocks of 128 rows) and on one sized for evaluation
+    for name, mb in [("inference configs[1], 60000 rows, blocks of 128 (a training handle)", 128),
+                     ("inference configs[1], 60000 rows, blocks of 16384", 16384)]:
+        try:
+            line = bc.run_inference("2", 60000, mb)
+            out[name] = {"samples_per_s": line["value"], "ms_per_pass": line["ms_per_pass"], "rows": line["rows"], "max_batch": mb,
+                         "per_block_calls_samples_per_s": line["per_block_calls_samples_per_s"], "dtype": "f32",
+                         "bound": line["roofline"]["bound"], "mfma_frac": line["roofline"]["frac"], "hbm_frac": line["roofline"]["hbm_frac"]}
+        except Exception as e:
+            out[name] = {"error": "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0])}
     return out
 
 

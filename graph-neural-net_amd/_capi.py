@@ -48,10 +48,12 @@ SYMBOLS = [
     ("gnn_mlp_train_range", C.c_int, [_H, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double]),
     ("gnn_mlp_loss_range", C.c_int, [_H, C.c_int64, C.c_int, _dp]),
     ("gnn_mlp_argmax_range", C.c_int, [_H, C.c_int64, C.c_int, _ip]),
+    ("gnn_mlp_count_hits_range", C.c_int, [_H, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     ("gnn_sampler_create", C.c_int, [C.c_int32, C.c_int64, C.POINTER(_H)]),
     ("gnn_sampler_destroy", C.c_int, [_H]),
     ("gnn_sampler_sample", C.c_int, [_H, C.c_int, _ip, C.POINTER(C.c_int)]),
     ("gnn_mlp_train_sampled", C.c_int, [_H, _H, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
+    ("gnn_mlp_train_sampled_observed", C.c_int, [_H, _H, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _dp]),
     ("gnn_mlp_grad_elems", C.c_int64, [_H]),
     ("gnn_mlp_grad_device_ptr", C.c_int, [_H, C.POINTER(C.c_void_p)]),
     ("gnn_mlp_bind_grad_buffer", C.c_int, [_H, C.c_void_p, C.c_int64]),

@@ -2,6 +2,8 @@
 // the handle's lifetime.  What a step is made of: plan.hip; kernels: launch_*.hip.
 #include "handle.h"
 
+#include <algorithm>
+
 #include <chrono>
 #include "java_random.h"
 
@@ -27,6 +29,8 @@ void read_env(gnn_mlp *h) {
     h->env_chain_off = is("GNN_MLP_CHAIN", "0");
     h->env_wavek_off = is("GNN_MLP_WAVEK", "0");
     h->env_rb_off = is("GNN_MLP_ROWBLOCK", "0");
+    const char *fg = getenv("GNN_MLP_FIRST_GEMM_ROWS"); // development: from how many rows on the first layer runs as a tiled GEMM (0 = never)
+    if (fg) h->first_gemm_rows = atoi(fg);
 }
 } // namespace
 
@@ -528,6 +532,32 @@ int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels) { 
     return read_labels(h, B, labels);
 }); }
 
+int gnn_mlp_count_hits_range(gnn_mlp_t *h, int64_t first, int64_t n, int64_t *hits) { return guarded([&]() -> int {
+    TRY(check_handle(h));
+    if (!hits) return fail(GNN_ERR_BAD_ARG, "null output");
+    if (!h->DX) return fail(GNN_ERR_STATE, "no dataset uploaded");
+    if (n <= 0 || first < 0 || first + n > h->dataset_n) return fail(GNN_ERR_BAD_ARG, "rows outside the dataset");
+    // one block of max_batch rows after the other on the stream: forward + output rule + `>=` argmax (labels), then the
+    // comparison with the expected class -- no host work and no readback between blocks
+    DevScratch cnt;
+    TRY(cnt.alloc(sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), h->stream));
+    const int Lm = h->L - 1;
+    for (int64_t off = 0; off < n; off += h->max_batch) {
+        const int B = (int)std::min<int64_t>(h->max_batch, n - off);
+        const float *y = h->DY + (size_t)(first + off) * h->ld[Lm];
+        do_forward(h, h->DX + (size_t)(first + off) * h->ld[0], nullptr, B, false, false, true);
+        hipLaunchKernelGGL(count_hits_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream,
+                           HitsParams{h->labels, y, h->ld[Lm], h->dims[Lm], B, cnt.as<unsigned long long>()});
+    }
+    TRY_LAUNCHES(h);
+    unsigned long long got = 0;
+    HIP_TRY(hipMemcpyAsync(&got, cnt.p, sizeof(got), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *hits = (int64_t)got;
+    return GNN_OK;
+}); }
+
 // ---- data-parallel hooks --------------------------------------------------------------------
 int gnn_mlp_grad_device_ptr(gnn_mlp_t *h, void **dev_ptr) { return guarded([&]() -> int {
     if (!h || !dev_ptr) return fail(GNN_ERR_BAD_ARG, "null argument");
@@ -591,11 +621,11 @@ int gnn_mlp_apply_update(gnn_mlp_t *h, int B_global, double step, double momentu
     return GNN_OK;
 }); }
 
-int gnn_mlp_forget_lookahead(gnn_mlp_t *h) {
+int gnn_mlp_forget_lookahead(gnn_mlp_t *h) { return guarded([&]() -> int {
     if (!h) return fail(GNN_ERR_BAD_ARG, "null handle");
     h->slab_valid = false; h->have_next = false; h->xstage_valid = false;
     return GNN_OK;
-}
+}); }
 
 int gnn_mlp_advance_time(gnn_mlp_t *h, int steps) { return guarded([&]() -> int {
     if (!h || h->time + steps < 0) return fail(GNN_ERR_BAD_ARG, "bad argument");

@@ -10,6 +10,7 @@
 #include "rowblock_kernel.h"
 #include "tile_step_kernel.h"
 #include "kernels.h"
+#include "eval_kernels.h"
 
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
@@ -126,6 +127,7 @@ struct gnn_mlp {
     bool env_jit_off = false;  // GNN_MLP_JIT=0
     bool env_static_off = false; // GNN_MLP_STATIC=0
     bool env_chain_off = false;  // GNN_MLP_CHAIN=0: three launches per step (fwd_first / middle4 / grad_update)
+    int first_gemm_rows = 2048;  // launch_fwd_first: blocks of at least this many rows take gemm_f32_kernel (GNN_MLP_FIRST_GEMM_ROWS; 0 = never)
     bool env_rb_off = false;     // GNN_MLP_ROWBLOCK=0: middle4_kernel<.., SLABS> as the two-launch step's row-block kernel (round 2's form)
 };
 
@@ -273,6 +275,10 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
                    bool want_loss, bool want_label, bool from_slabs = false, int copy_rows = RB_COPY_NONE);
 void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, const float *a0, int B, float step_over_b, float momentum,
                       bool staged = false, const PeerGradients *peers = nullptr, bool next_staged = false);
+
+// ---- sampler.hip ---------------------------------------------------------------------------------
+// validate(validation_size) (NNT:102-113) on the device: the summed loss of dataset rows [0, n) into *d_out (fp64, device)
+int validation_loss_sum(gnn_mlp *h, int n, double *d_out);
 
 // ---- launch_misc.hip: encodings, gathers, the flat update ---------------------------------------
 void launch_convert_rows(gnn_mlp *h, const double *src, int d, float *dst, int ld, int64_t rows, int64_t rows_pad, int act, int apply_act);

@@ -152,6 +152,21 @@ void backward(gnn_mlp *h, const float *a0, int B, bool fused_update, float step_
 // first layer in one launch: a 16x16 tile per workgroup, K split over the waves
 void launch_fwd_first(gnn_mlp *h, const float *a0, int B) {
     const int B_pad = pad_up(B);
+    // Blocks of thousands of rows (evaluation over the training set, MT:181-197, walks 60 000 of them in blocks of max_batch): the
+    // one-tile-per-workgroup kernel below is built for a FEW 16 x 16 tiles with K split over the waves -- at 4 096 rows it ran
+    // the 784 x 300 product at 36 TFLOP/s (53 us of an 80-us block, profiles/r04/inference_kernel_stats_before.csv); the tiled
+    // GEMM takes over from first_gemm_rows rows (rows addressed directly only: it does not gather).
+    if (h->first_gemm_rows > 0 && B_pad >= h->first_gemm_rows && !h->cur_idx) {
+        GemmParams p{};
+        p.A = a0; p.lda = h->ld[0];
+        p.B = h->W; p.ldb = h->ld[1];
+        p.C = h->act[1]; p.ldc = h->ld[1];
+        p.M = B_pad; p.N = h->ld[1]; p.K = h->ld[0];
+        p.m_true = B; p.n_true = h->dims[1];
+        p.act = h->inner_act;
+        launch_gemm<true, false, EPI_ACT>(h, GNN_K_FWD_GEMM0, p);
+        return;
+    }
     FwdFirstParams f{};
     f.A = a0; f.lda = h->ld[0];
     f.W = h->W; f.ldw = h->ld[1];

@@ -239,7 +239,12 @@ void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_pr
         run_output(h, y, B, want_prob, false, want_loss, want_label);
         return;
     }
-    if (h->mid4) { fused_forward(h, a0, y, B, false, want_prob, want_loss, want_label); return; }
+    // Blocks of thousands of rows (evaluation over a whole data set, gnn_mlp_count_hits_range): the row-block kernel re-reads every
+    // middle weight per FOUR rows and the one-tile first layer is built for a few tiles -- from first_gemm_rows rows on the forward
+    // pass is the per-layer GEMM chain (+ the tail kernel), each weight matrix read once per 64-row tile
+    // (784-300-100-10, 60 000 rows in blocks of 16 384: 52.9 -> 75 M rows/s with the first layer alone, profiles/r04/inference_sweep.log)
+    const bool big_block = h->first_gemm_rows > 0 && pad_up(B) >= h->first_gemm_rows && !h->cur_idx;
+    if (h->mid4 && !big_block) { fused_forward(h, a0, y, B, false, want_prob, want_loss, want_label); return; }
     const bool tail = use_tail(h);
     if (h->mid_generic && hybrid_choice(h, B).first) {
         launch_fwd_first(h, a0, B);

@@ -4,6 +4,7 @@
 #include "java_random.h"
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -94,8 +95,28 @@ int gnn_sampler_sample(gnn_sampler_t *s, int batch, int32_t *out_idx, int *n_out
     return GNN_OK;
 }); }
 
-int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step, double momentum,
-                          int noise) { return guarded([&]() -> int {
+} // extern "C"
+
+namespace gnn {
+namespace host {
+// validate(validation_size) of NNT:102-113 without its division: calculateLoss over the first n samples in master order
+// (dataset rows [0, n)), block by block on the handle's stream, summed into ONE fp64 slot on the device.
+int validation_loss_sum(gnn_mlp *h, int n, double *d_out) {
+    const int Lm = h->L - 1;
+    for (int off = 0; off < n; off += h->max_batch) {
+        const int B = std::min(h->max_batch, n - off);
+        do_forward(h, h->DX + (size_t)off * h->ld[0], h->DY + (size_t)off * h->ld[Lm], B, false, true, false);
+        hipLaunchKernelGGL(sum_loss_kernel, dim3(1), dim3(256), 0, h->stream, LossSumParams{h->lossv, B, d_out, off > 0 ? 1 : 0});
+    }
+    return GNN_OK;
+}
+} // namespace host
+} // namespace gnn
+
+// The loop NNT:60-92 on a resident dataset; d_val != null: the observed variants (NNT:68-72, 75-79) -- after iteration i the
+// summed validation loss of rows [0, validation_size) goes to d_val[i] (device).
+static int train_sampled_impl(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step, double momentum,
+                              int noise, int validation_size, double *d_val) {
     TRY(check_handle(h));
     if (!s) return fail(GNN_ERR_BAD_ARG, "null sampler");
     TRY(check_step_args(h, batch, step, noise));
@@ -122,7 +143,17 @@ int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int ba
     while (chunk_begin(n_chunks) < iterations) n_chunks++;
     auto chunk_end = [&](int c) { return std::min(iterations, chunk_begin(c + 1)); };
     const size_t slot_elems = (size_t)kChunk * batch;
-    std::vector<int32_t> idx(slot_elems * kRing);
+    // The host ring is PINNED memory and every upload is followed by an event: the copy is then truly asynchronous (from pageable
+    // memory hipMemcpyAsync stages the data before it returns -- in this runtime by waiting for the stream, i.e. for every step
+    // queued so far: the GPU idled at each chunk boundary, and the slot's safety rested on that behaviour), and a host slot goes
+    // back to the sampler only when its event has completed.
+    struct PinnedRing {
+        int32_t *p = nullptr; hipEvent_t ev[kRing] = {};
+        ~PinnedRing() { if (p) (void)hipHostFree(p); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+    } ring;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ring.p), slot_elems * kRing * sizeof(int32_t), hipHostMallocDefault));
+    for (int i = 0; i < kRing; i++) HIP_TRY(hipEventCreateWithFlags(&ring.ev[i], hipEventDisableTiming));
+    int32_t *const idx = ring.p;
     std::vector<int> cnt((size_t)kChunk * kRing);
     struct Shared {
         std::mutex mu;
@@ -140,7 +171,7 @@ int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int ba
             }
             int rc = GNN_OK;
             const int i0 = chunk_begin(c), i1 = chunk_end(c);
-            int32_t *slot = idx.data() + (size_t)(c % kRing) * slot_elems;
+            int32_t *slot = idx + (size_t)(c % kRing) * slot_elems;
             int *scnt = cnt.data() + (size_t)(c % kRing) * kChunk;
             for (int i = i0; i < i1 && rc == GNN_OK; i++) rc = gnn_sampler_sample(s, batch, slot + (size_t)(i - i0) * batch, &scnt[i - i0]);
             std::lock_guard<std::mutex> lk(sh.mu);
@@ -166,23 +197,50 @@ int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int ba
     // two-launch steps runs through the chunk boundary -- an upload in stream order at the boundary left the GPU idle for
     // the copy and restarted the chain with a forward-only launch, ~1 us per step over a run.
     int uploaded = 0; // chunks whose draws are on the device (or in flight in front of every launch that reads them)
+    int released = 0; // chunks whose HOST slot is the sampler's again (their upload's event has completed)
     auto upload = [&](int c) -> int {
         const int j0 = chunk_begin(c), j1 = chunk_end(c);
         const size_t so = (size_t)(c % kRing) * slot_elems;
-        // (pageable hipMemcpyAsync returns once the host data has been consumed: the host slot is then free for the sampler.  The
-        //  counts are copied out of the ring first: the sampler may refill the host slot from here on.)
+        // (the counts are copied out of the ring at once; the indices stay in the pinned slot until the copy has run)
         std::copy(cnt.begin() + (size_t)(c % kRing) * kChunk, cnt.begin() + (size_t)(c % kRing) * kChunk + (j1 - j0), dcnt.begin() + (size_t)(c % kRing) * kChunk);
-        const hipError_t e = hipMemcpyAsync(d_idx + so, idx.data() + so, (size_t)(j1 - j0) * batch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+        hipError_t e = hipMemcpyAsync(d_idx + so, idx + so, (size_t)(j1 - j0) * batch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipEventRecord(ring.ev[c % kRing], h->stream);
         if (e != hipSuccess) return fail(GNN_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
-        { std::lock_guard<std::mutex> lk(sh.mu); sh.consumed = c + 1; }
-        sh.cv.notify_all();
         uploaded = c + 1;
         return GNN_OK;
     };
+    // hands finished uploads' host slots back to the sampler: those whose event has completed -- all of them when `wait`
+    // (an upload sits in front of the steps of the chunk BEFORE its own, so by the time the sampler needs the slot,
+    //  kRing chunks later, the copy ran long ago: the wait does not stall)
+    auto release = [&](bool wait) -> int {
+        int r = released;
+        while (r < uploaded) {
+            const hipError_t q = (wait && r == released) ? hipEventSynchronize(ring.ev[r % kRing]) : hipEventQuery(ring.ev[r % kRing]); // (wait: for the OLDEST one)
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) return fail(GNN_ERR_HIP, std::string("upload event: ") + hipGetErrorString(q));
+            r++;
+        }
+        if (r != released) {
+            released = r;
+            { std::lock_guard<std::mutex> lk(sh.mu); sh.consumed = r; }
+            sh.cv.notify_all();
+        }
+        return GNN_OK;
+    };
     for (int c = 0; c < n_chunks && rc == GNN_OK; c++) {
+        rc = release(false);
+        if (rc != GNN_OK) break;
         if (uploaded <= c) {
             std::unique_lock<std::mutex> lk(sh.mu);
-            sh.cv.wait(lk, [&] { return sh.ready > c; });
+            // (the sampler may be waiting for a host slot whose upload is still in flight: hand slots back while waiting for it)
+            while (!(sh.ready > c)) {
+                lk.unlock();
+                rc = release(uploaded - released >= kRing); // every slot taken and none released: wait for the oldest upload
+                lk.lock();
+                if (rc != GNN_OK || sh.ready > c) break;
+                sh.cv.wait_for(lk, std::chrono::microseconds(200));
+            }
+            if (rc != GNN_OK) break;
             if (sh.sampler_rc != GNN_OK) { rc = fail(sh.sampler_rc, sh.sampler_msg); break; }
             lk.unlock();
             rc = upload(c);
@@ -204,12 +262,37 @@ int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int ba
                 h->have_next = true; h->next_a0 = h->DX; h->next_idx = d_idx + sn; h->next_B = dcnt[(size_t)((c + 1) % kRing) * kChunk];
             }
             rc = step_on_device_indices(h, d_idx + so + (size_t)(i - i0) * batch, ccnt[i - i0], step, momentum);
+            // (the validation pass reads the weights the step has just written; it touches neither the slabs the step's tile
+            //  kernel made for the next batch nor the staged rows, so the chain of two-launch steps runs on behind it)
+            if (rc == GNN_OK && d_val) rc = validation_loss_sum(h, validation_size, d_val + i);
         }
     }
     // (on an early exit the sampler stops after the chunk it is drawing: its state stays well defined)
     (void)hipStreamSynchronize(h->stream); // the device ring is released below
     h->slab_valid = false; h->have_next = false; // (they may name rows through d_idx)
     return rc;
+}
+
+extern "C" {
+
+int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step, double momentum,
+                          int noise) { return guarded([&]() -> int {
+    return train_sampled_impl(h, s, iterations, batch, step, momentum, noise, 0, nullptr);
+}); }
+
+int gnn_mlp_train_sampled_observed(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step, double momentum,
+                                   int noise, int validation_size, double *val_loss) { return guarded([&]() -> int {
+    TRY(check_handle(h));
+    if (!val_loss) return fail(GNN_ERR_BAD_ARG, "null output");
+    if (iterations <= 0) return fail(GNN_ERR_BAD_ARG, "iterations must be positive (NNT:62)");
+    if (validation_size <= 0 || validation_size > h->dataset_n) return fail(GNN_ERR_BAD_ARG, "validation size outside the dataset (NNT:104)");
+    DevScratch dv;
+    TRY(dv.alloc(sizeof(double) * (size_t)iterations));
+    TRY(train_sampled_impl(h, s, iterations, batch, step, momentum, noise, validation_size, dv.as<double>()));
+    // (train_sampled_impl has waited for the stream: every sum is in place)
+    HIP_TRY(hipMemcpy(val_loss, dv.p, sizeof(double) * (size_t)iterations, hipMemcpyDeviceToHost));
+    for (int i = 0; i < iterations; i++) val_loss[i] /= (double)validation_size; // NNT:112
+    return GNN_OK;
 }); }
 
 } // extern "C"

@@ -225,6 +225,14 @@ class NeuralNet:
                                                    out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
+    def count_hits_range(self, first=0, n=None):
+        """testOnTrainingData / testOnTestData (MT:159-197) over dataset rows [first, first + n): the number of rows whose `>=`
+        argmax equals the expected class (the last index whose expected value is 1); one readback."""
+        n = self.dataset_size - int(first) if n is None else int(n)
+        out = C.c_int64()
+        _capi.check(self._lib.gnn_mlp_count_hits_range(self._h, int(first), n, C.byref(out)))
+        return out.value
+
     # -- data-parallel hooks ------------------------------------------------------------------
     @property
     def grad_elems(self):

@@ -70,14 +70,44 @@ class NeuralNetTrainer:
                                                             int(batchSize), float(stepSize), float(momentum),
                                                             int(bool(noise))))
             return
-        for i in range(iterations):                                  # NNT:68-86
+        if observer is None:                                         # only progress monitored, NNT:75-79 has no validation
+            done = 0
+            while done < iterations:                                 # (the monitor steps in bursts: a device loop per burst)
+                n = min(self.OBSERVER_BURST, iterations - done)
+                _capi.check(self.net._lib.gnn_mlp_train_sampled(self.net._h, self.sampler._h, n, int(batchSize), float(stepSize),
+                                                                float(momentum), int(bool(noise))))
+                for _ in range(n):
+                    monitor.step()
+                done += n
+            monitor.finish()
+            return
+        # observed (NNT:68-72 with a monitor, NNT:75-79 without): gradientStep + validate(validationSize) per iteration, both on
+        # the device; the validation losses of a burst come back in ONE readback and are printed in the reference's format
+        done = 0
+        while done < iterations:
+            n = min(self.OBSERVER_BURST, iterations - done) if monitor is not None else iterations - done
+            val = np.empty(n)
+            _capi.check(self.net._lib.gnn_mlp_train_sampled_observed(
+                self.net._h, self.sampler._h, n, int(batchSize), float(stepSize), float(momentum), int(bool(noise)),
+                int(validation_size), val.ctypes.data_as(C.POINTER(C.c_double))))
+            for k in range(n):
+                observer.write("%d,%.2f\n" % (done + k, val[k]))      # NNT:71
+                if monitor is not None:
+                    monitor.step()
+            done += n
+        if monitor is not None:
+            monitor.finish()
+
+    OBSERVER_BURST = 256   # iterations per device loop when a progress monitor wants to be stepped
+
+    def train_stepwise(self, iterations, stepSize, batchSize, momentum, noise=False, observer=None):
+        """The observed loop NNT:75-79 one ABI call per action (sample on the host, an indexed step, a validation readback per
+        iteration) -- the form `train` had until round 4; kept for the tests that compare the device loop against it."""
+        validation_size = self.size // 100 + 1
+        for i in range(iterations):
             self.net.gradient_step_indexed(self.sampler.sample(batchSize), stepSize, momentum, noise)
             if observer is not None:
                 observer.write("%d,%.2f\n" % (i, self.validate(validation_size)))
-            if monitor is not None:
-                monitor.step()
-        if monitor is not None:
-            monitor.finish()
 
     def validate(self, batchSize):
         """NNT:102-113: mean loss over the first batchSize samples in master order."""
@@ -114,9 +144,13 @@ def read_idx_labels(path):
     return data
 
 
-def accuracy(net, labels, first=0):
+def accuracy(net, labels=None, first=0, n=None):
     """testOnTrainingData / testOnTestData (MT:159-197) over dataset rows [first, first+len):
-    hit when the `>=` argmax of propagate() equals the label."""
+    hit when the `>=` argmax of propagate() equals the label.  With labels = None the expected classes are the dataset's own
+    expected rows (MT:186-188) and the whole loop runs on the device (gnn_mlp_count_hits_range: one readback)."""
+    if labels is None:
+        n = net.dataset_size - first if n is None else n
+        return net.count_hits_range(first, n) / n
     labels = np.asarray(labels)
     hits, off = 0, 0
     while off < labels.size:

@@ -158,6 +158,11 @@ int gnn_mlp_train_range(gnn_mlp_t *h, int64_t first, int B, int n_steps, double 
                         double momentum);
 int gnn_mlp_loss_range(gnn_mlp_t *h, int64_t first, int B, double *loss_per_sample);
 int gnn_mlp_argmax_range(gnn_mlp_t *h, int64_t first, int B, int32_t *labels);
+/* testOnTrainingData / testOnTestData (MT:159-197) over the dataset rows [first, first + n), any n: propagate + the `>=`
+ * argmax (MT:166-168) per row, a hit when it equals the expected class -- the LAST index whose expected value is 1
+ * (MT:186-188; for the one-hot rows of MT:112-118 that is the label).  The rows are walked in blocks of max_batch with no host
+ * work in between; ONE count comes back.  The reference returns hits / size (MT:172, 197): the division is the caller's. */
+int gnn_mlp_count_hits_range(gnn_mlp_t *h, int64_t first, int64_t n, int64_t *hits);
 
 /* ---- the trainer's sampling loop (NeuralNetTrainer.java) ------------------------------------ */
 
@@ -176,6 +181,13 @@ int gnn_sampler_sample(gnn_sampler_t *s, int batch, int32_t *out_idx, int *n_out
  * are made up front and uploaded once; the steps are then enqueued with no host->device copy. */
 int gnn_mlp_train_sampled(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step,
                           double momentum, int noise);
+/* The OBSERVED loops NNT:68-72 / NNT:75-79: `iterations` times { sample(batch); gradientStep; validate(validation_size) }.
+ * validate (NNT:102-113) is the mean of calculateLoss over the first validation_size samples in master order -- here dataset
+ * rows [0, validation_size).  Steps and validation passes are enqueued back to back; the summed losses stay in a device buffer
+ * and come back ONCE: val_loss[i] = validate(validation_size) after iteration i (the value the reference prints as "%d,%.2f",
+ * NNT:71).  Needs 0 < validation_size <= the dataset's size. */
+int gnn_mlp_train_sampled_observed(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step,
+                                   double momentum, int noise, int validation_size, double *val_loss);
 
 /* ---- data-parallel hooks (one process per GPU; the exchange is the caller's collective) -- */
 
@@ -204,14 +216,15 @@ int gnn_mlp_synchronize(gnn_mlp_t *h);
  * gnn_mlp_set_stream) replays device work the host-side `time` counter (SCE:343) does not see;
  * it reports the replayed steps here (and takes back, with a negative count, the steps that
  * were only captured, not executed). */
+int gnn_mlp_advance_time(gnn_mlp_t *h, int steps);
 /* Drops what the handle remembers about work done AHEAD of the next gradient computation (the next batch's first-layer
  * sums made by the previous step's tile kernel, a pending gnn_mlp_hint_next_range).  The next gradient computation then
  * starts its own chain: results are unchanged (bitwise), one extra launch.  A caller that captures
  * gnn_mlp_compute_gradient_range / gnn_mlp_apply_update into a HIP graph itself MUST call this before the capture begins
  * (so that the captured sequence does not depend on what ran before it), after it ends, and after every replay (the host
- * bookkeeping describes the captured pass, not what the device then holds); gnn_mlp_train_range does so by itself. */
+ * bookkeeping describes the captured pass, not what the device then holds).  gnn_mlp_train_range's own captured pass
+ * (GNN_MLP_GRAPH=1) is a closed chain -- it starts and ends on the same batch -- and keeps that bookkeeping consistent itself. */
 int gnn_mlp_forget_lookahead(gnn_mlp_t *h);
-int gnn_mlp_advance_time(gnn_mlp_t *h, int steps);
 /* After a stream capture that FAILED (e.g. a collective that cannot be captured invalidated it):
  * ends a capture still open on the handle's stream, discards its graph and clears the sticky HIP
  * error of the calling thread, so that eager calls work again; if the runtime keeps the stream

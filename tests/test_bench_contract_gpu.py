@@ -59,6 +59,12 @@ def test_bench_line_single_process():
         assert "error" not in oc[name], oc[name]
         assert oc[name]["samples_per_s"] > 0 and oc[name]["us_per_step_events"] > 0
     assert oc["configs[4] f32 hipGraph"]["hipgraph"] is True
+    for name in ("configs[1] GeneralNeuralNet sigmoid", "configs[1] GeneralNeuralNet leaky_relu/sigmoid"):
+        assert "error" not in oc[name] and oc[name]["samples_per_s"] > 0
+    inf = [k for k in oc if k.startswith("inference configs[1]")]
+    assert len(inf) == 2
+    for k in inf:   # evaluation over MNIST's 60 000 rows as one call (MT:181-197), beside the same loop one call per block
+        assert "error" not in oc[k] and oc[k]["samples_per_s"] > oc[k]["per_block_calls_samples_per_s"] > 0
 
 
 def test_bench_line_bf16():

@@ -32,7 +32,7 @@ def test_train_equals_stepwise_and_oracle(gnn, oracle_mod):
     tb = gnn.NeuralNetTrainer(X, Y, b)
     ta.train(iters, 0.01, B, 0.9, False)                      # gnn_mlp_train_sampled
     obs = io.StringIO()
-    tb.train(iters, 0.01, B, 0.9, False, observer=obs)        # per-iteration path with validation
+    tb.train(iters, 0.01, B, 0.9, False, observer=obs)        # the observed loop: steps + validation passes on the device
     assert a.time == iters == b.time
     assert np.array_equal(a.get_weights(), b.get_weights())
     lines = obs.getvalue().strip().split("\n")
@@ -133,3 +133,103 @@ def test_train_sampled_ragged_batches_and_chunks(gnn, oracle_mod):
     assert a.time == iters == b.time
     assert np.array_equal(a.get_weights(), b.get_weights())
     assert np.array_equal(a.get_momentum(), b.get_momentum())
+
+
+def test_count_hits_range_is_the_reference_test_loop(gnn, oracle_mod):
+    """gnn_mlp_count_hits_range = testOnTrainingData / testOnTestData (MT:159-197) on the device: rows walked in blocks of
+    max_batch (a ragged last block), `>=` argmax against the expected class (the LAST index holding 1, MT:186-188), one count.
+    Against the per-block argmax_range loop (same kernels: equal), and against the oracle's propagate + argmax rule on every
+    row whose top-2 logit margin is safe."""
+    dims, N, B = [784, 100, 50, 10], 1000, 128          # 7 full blocks + 104 rows
+    rng = np.random.default_rng(8)
+    lab = rng.integers(0, 10, N)
+    proto = rng.random((10, 784)) * (rng.random((10, 784)) < 0.2)
+    X = np.clip(proto[lab] + 0.15 * rng.standard_normal((N, 784)) * (proto[lab] > 0), 0, 1)
+    Y = np.eye(10)[lab]
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    trainer = gnn.NeuralNetTrainer(X, Y, net)
+    trainer.train(60, 0.01, 32, 0.9, False)             # somewhere between chance and perfect
+    hits = net.count_hits_range(0, N)
+    by_blocks = sum(int((net.argmax_range(f, min(B, N - f)) == lab[f:f + B]).sum()) for f in range(0, N, B))
+    assert hits == by_blocks
+    assert gnn.accuracy(net) == hits / N == gnn.accuracy(net, lab)
+    assert net.count_hits_range(100, 333) == sum(int((net.argmax_range(f, min(B, 433 - f)) == lab[f:min(f + B, 433)]).sum()) for f in range(100, 433, B))
+    ref = oracle_mod.OracleNet(dims)
+    ref.set_weights(net.get_weights())
+    logits = ref.logits(X)
+    s = np.sort(logits, axis=1)
+    safe = (s[:, -1] - s[:, -2]) > 1e-3
+    want = ref.argmax(X)
+    assert abs(hits - int((want == lab).sum())) <= int((~safe).sum())
+    assert 0.2 < hits / N <= 1.0
+    # an expected row with two ones: the LAST one counts (MT:186-188); with none: class 0
+    Y2 = Y.copy(); Y2[0] = 0; Y2[0, 2] = 1; Y2[0, 7] = 1; Y2[1] = 0
+    net.upload_dataset(X, Y2)
+    lab2 = lab.copy(); lab2[0] = 7; lab2[1] = 0
+    assert net.count_hits_range(0, 2) == int((net.argmax_range(0, 2) == lab2[:2]).sum())
+    with pytest.raises(gnn.GnnError):
+        net.count_hits_range(N - 5, 6)
+
+
+class _Monitor:
+    def __init__(self): self.steps, self.finished = 0, 0
+    def step(self): self.steps += 1
+    def finish(self): self.finished += 1
+
+
+def test_observed_training_loops_run_on_the_device(gnn, oracle_mod):
+    """NNT:68-72 / 75-79: gradientStep + validate(validationSize) per iteration.  gnn_mlp_train_sampled_observed keeps both on the
+    device (the validation losses of a call come back in one readback) -- against the same loop made of one ABI call per
+    action (host sampler, indexed step, a loss readback per iteration): the SAME weights bit for bit, the same validation
+    losses up to the order of an fp64 sum of the same f32 values, the reference's line format; and the oracle's validate()."""
+    dims, N, B, iters = [784, 100, 50, 10], 640, 32, 45     # validation size 7; two epochs and a bit
+    rng = np.random.default_rng(12)
+    pix = rng.integers(0, 256, (N, 784), dtype=np.uint8)
+    pix[rng.random((N, 784)) < 0.8] = 0
+    lab = rng.integers(0, 10, N, dtype=np.uint8)
+    X, Y = pix / 255.0, np.eye(10)[lab]
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    c = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=4)   # validation size 7 > max_batch: two blocks per validation pass
+    ta, tb, tc = gnn.NeuralNetTrainer(pix, lab, a, raw_u8=True), gnn.NeuralNetTrainer(pix, lab, b, raw_u8=True), gnn.NeuralNetTrainer(pix, lab, c, raw_u8=True)
+    oa, ob, oc = io.StringIO(), io.StringIO(), io.StringIO()
+    mon = _Monitor()
+    ta.OBSERVER_BURST = 16                                   # three device loops: 16 + 16 + 13 iterations
+    ta.train(iters, 0.01, B, 0.9, False, monitor=mon, observer=oa)
+    tb.train_stepwise(iters, 0.01, B, 0.9, False, observer=ob)
+    assert mon.steps == iters and mon.finished == 1
+    assert a.time == iters == b.time
+    assert np.array_equal(a.get_weights(), b.get_weights()) and np.array_equal(a.get_momentum(), b.get_momentum())
+    la, lb = oa.getvalue().strip().split("\n"), ob.getvalue().strip().split("\n")
+    assert len(la) == iters == len(lb)
+    for i, (x, y) in enumerate(zip(la, lb)):
+        assert x.split(",")[0] == str(i) == y.split(",")[0]
+        assert len(x.split(",")[1].split(".")[1]) == 2                          # "%d,%.2f" (NNT:71)
+        assert abs(float(x.split(",")[1]) - float(y.split(",")[1])) <= 0.0100001   # (a sum that rounds the other way at a .005)
+    # the unrounded values, straight from the ABI, against the oracle's validate() on the oracle's trajectory
+    import ctypes as C
+    vs = N // 100 + 1
+    val = np.empty(10)
+    d = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    td = gnn.NeuralNetTrainer(pix, lab, d, raw_u8=True)
+    gnn.load_library().gnn_mlp_train_sampled_observed(d._h, td.sampler._h, 10, B, 0.01, 0.9, 0, vs, val.ctypes.data_as(C.POINTER(C.c_double)))
+    ref = oracle_mod.OracleNet(dims)
+    ref.set_alloc_per_sample(0)
+    smp = oracle_mod.Sampler(N)
+    for i in range(10):
+        idx = smp.sample(B)
+        ref.gradient_step(X[idx], Y[idx], 0.01, 0.9)
+        vr = float(ref.calculate_loss(X[:vs], Y[:vs]).mean())                    # NNT:102-113
+        assert abs(val[i] - vr) <= 2e-4 * abs(vr) + 2e-4, (i, val[i], vr)
+    # observer only (NNT:75-79), validation rows in two blocks: the same steps again
+    tc.train(iters, 0.01, 4, 0.9, False, observer=oc)
+    assert c.time == iters and len(oc.getvalue().strip().split("\n")) == iters
+    # monitor only (NNT:82-86): no validation, the device loop in bursts
+    e = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    te = gnn.NeuralNetTrainer(pix, lab, e, raw_u8=True)
+    te.OBSERVER_BURST = 20
+    m2 = _Monitor()
+    te.train(iters, 0.01, B, 0.9, False, monitor=m2)
+    assert m2.steps == iters and m2.finished == 1 and np.array_equal(e.get_weights(), a.get_weights())
+    with pytest.raises(gnn.GnnError):
+        gnn._capi.check(gnn.load_library().gnn_mlp_train_sampled_observed(d._h, td.sampler._h, 3, B, 0.01, 0.9, 0, N + 1, val.ctypes.data_as(C.POINTER(C.c_double))))

@@ -120,8 +120,47 @@ def run(key, dtype, steps, graph=False, n_batches=8, timed_kernels=True, general
     return line
 
 
+def run_inference(key="2", rows=60000, max_batch=4096, reps=5, dtype="f32"):
+    """testOnTrainingData (MT:181-197) as ONE call: propagate + the `>=` argmax + the comparison with the expected class over
+    `rows` resident 784-pixel rows (MNIST's training-set size), gnn_mlp_count_hits_range -- blocks of max_batch rows, no host work
+    in between, one count read back.  Algorithmic work per row: 2 P FLOP (the forward products), d_0 x 4 bytes of input;
+    arithmetic intensity ~170 FLOP/B, far above the f32 ridge: quoted against the MFMA peak."""
+    dims, _, label = CONFIGS[key]
+    rng = np.random.default_rng(1)
+    pix = rng.integers(0, 256, (rows, dims[0]), dtype=np.uint8)
+    pix[rng.random((rows, dims[0])) < 0.8] = 0
+    lab = rng.integers(0, dims[-1], rows, dtype=np.uint8)
+    net = gnn_amd.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn_amd.DTYPE_BF16 if dtype == "bf16" else gnn_amd.DTYPE_F32, max_batch=max_batch)
+    net.upload_dataset_u8(pix, lab)
+    hits = net.count_hits_range(0, rows)     # warm (and the answer: ~10 % of a random net's labels are right)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        assert net.count_hits_range(0, rows) == hits
+    dt = (time.perf_counter() - t0) / reps
+    # the same loop one ABI call per block (argmax_range + a comparison on the host): the only form until round 4
+    t1 = time.perf_counter()
+    per_block = sum(int((net.argmax_range(f, min(max_batch, rows - f)) == lab[f:f + max_batch]).sum()) for f in range(0, rows, max_batch))
+    dt_blocks = time.perf_counter() - t1
+    assert per_block == hits
+    P = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1))
+    flop = 2.0 * P * rows
+    nbytes = 4.0 * rows * (dims[0] + 1) + 4.0 * P
+    tf = flop / dt / 1e12
+    out = {"metric": "inference samples/sec (propagate + argmax + hit count, MT:181-197), %s" % label.split(":")[0], "value": round(rows / dt, 1),
+           "unit": "samples/s", "rows": rows, "max_batch": max_batch, "ms_per_pass": round(dt * 1e3, 4), "dtype": dtype, "hits": int(hits),
+           "per_block_calls_samples_per_s": round(rows / dt_blocks, 1),
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TF[dtype], "unit": "TFLOP/s", "frac": round(tf / PEAK_TF[dtype], 4),
+                        "flop_per_pass": flop, "algorithmic_bytes_per_pass": nbytes, "hbm_frac": round(nbytes / dt / 1e9 / HBM_GBS, 4)}}
+    net.close()
+    return out
+
+
 def main():
     args = sys.argv[1:]
+    if args and args[0] == "inference":
+        for mb in [int(a) for a in args[1:]] or [128, 1024, 4096, 16384]:
+            print(json.dumps(run_inference(max_batch=mb)), flush=True)
+        return
     steps = None
     if "--steps" in args:
         i = args.index("--steps")
