@@ -3,6 +3,7 @@
 // g++ -fsanitize=thread.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
@@ -16,6 +17,9 @@ namespace host {
 inline void rows_to_f32_plain(const double *src, float *dst, size_t n) {
     for (size_t i = 0; i < n; i++) dst[i] = (float)src[i];
 }
+// (the x86 specifics -- an AVX2 clone of the loop, the spin-wait hint -- sit behind the architecture test: the host side of the
+//  library builds on any host the HIP toolchain targets)
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) inline void rows_to_f32_avx2(const double *src, float *dst, size_t n) {
     for (size_t i = 0; i < n; i++) dst[i] = (float)src[i]; // (vectorised by the compiler: vcvtpd2ps)
 }
@@ -24,6 +28,11 @@ inline void rows_to_f32(const double *src, float *dst, size_t n) {
     if (avx2) rows_to_f32_avx2(src, dst, n);
     else rows_to_f32_plain(src, dst, n);
 }
+inline void cpu_relax() { __builtin_ia32_pause(); }
+#else
+inline void rows_to_f32(const double *src, float *dst, size_t n) { rows_to_f32_plain(src, dst, n); }
+inline void cpu_relax() { std::atomic_signal_fence(std::memory_order_seq_cst); }
+#endif
 
 // The conversion is the call's largest host cost (0.8 MB read, 0.4 MB written per 128-row batch of 784 inputs: ~20 us on
 // one core).  Up to three helper threads per process (GNN_MLP_CONVERT_THREADS = 0..3 overrides; one on small hosts) share
@@ -61,7 +70,12 @@ class ConvertHelper {
             cv_.notify_all();
         }
         claim_pieces(job, 0);
-        while (completed_.v.load(std::memory_order_acquire) != pieces) __builtin_ia32_pause(); // (pieces in other hands: ~1 us each)
+        // pieces in other hands: ~1 us each.  A helper that the scheduler took off its core mid-piece (a busy host: a JVM's own
+        // threads) would keep a spinning caller waiting for a time slice, so after a short spin the caller yields its core
+        for (unsigned spins = 0; completed_.v.load(std::memory_order_acquire) != pieces; spins++) {
+            if (spins < kSpinsBeforeYield) cpu_relax();
+            else std::this_thread::yield();
+        }
     }
 
   private:
@@ -90,14 +104,18 @@ class ConvertHelper {
     void work(int me) {
         uint64_t seen = 0;
         for (;;) {
-            uint64_t s, t0 = __builtin_ia32_rdtsc();
+            using clock = std::chrono::steady_clock;
+            uint64_t s;
+            clock::time_point t0 = clock::now();
+            unsigned polls = 0;
             while ((s = seq_.load()) == seen && !quit_.load(std::memory_order_relaxed)) {
-                if (__builtin_ia32_rdtsc() - t0 < kPollTicks) { __builtin_ia32_pause(); continue; }
+                // (the clock is read every 64th poll: ~25 ns per reading against ~40 ns per pause)
+                if ((++polls & 63) != 0 || clock::now() - t0 < kPollWindow) { cpu_relax(); continue; }
                 std::unique_lock<std::mutex> lk(mu_);
                 sleepers_.fetch_add(1);
                 cv_.wait(lk, [&] { return seq_.load() != seen || quit_.load(); });
                 sleepers_.fetch_sub(1);
-                t0 = __builtin_ia32_rdtsc();
+                t0 = clock::now();
             }
             if (quit_.load()) return;
             seen = s;
@@ -123,8 +141,10 @@ class ConvertHelper {
         n_helpers_ = made;
         return made > 0;
     }
-    static constexpr uint64_t kPollTicks = 1500000; // ~0.5 ms of the time-stamp counter: several periods of the slowest loop that gains from helpers
-                                                  // (a window near the period itself lets the helpers fall asleep before every call)
+    // how long a helper polls for the next batch before it sleeps: several periods of the slowest loop that gains from helpers
+    // (a window near the period itself lets the helpers fall asleep before every call) -- wall-clock time, whatever the host's clock rate
+    static constexpr std::chrono::microseconds kPollWindow{500};
+    static constexpr unsigned kSpinsBeforeYield = 4096; // ~150 us of pauses: twenty pieces' worth
     std::mutex mu_, call_mu_;
     std::condition_variable cv_;
     std::thread th_[kMaxHelpers];

@@ -74,6 +74,9 @@ struct gnn_mlp_dp {
     std::vector<hipEvent_t> scat_done;
     int64_t slice = 0;                            // floats per owner, a multiple of 16
     int64_t steps = 0;
+    // a step that failed AFTER some replica's work was enqueued (a refused launch, a failed event call): the replicas may no
+    // longer hold the same weights / step count / buffer parity -- every later step is refused instead of training on silently
+    bool broken = false;
 };
 
 namespace {
@@ -171,9 +174,12 @@ int dp_reduce_and_update(gnn_mlp_dp *d, int B_global, double step, double moment
             h->slab_valid = false; h->have_next = false;
         }
         HIP_TRY(hipEventRecord(d->red_done[par][r], h->stream));
-        h->time++;
-        TRY_LAUNCHES(h);
     }
+    // every replica's update is enqueued: one check over all of them, then the step counts for all or for none
+    int rc = GNN_OK;
+    for (int r = 0; r < n; r++) { const int e = check_launches(d->rep[r]); if (e != GNN_OK && rc == GNN_OK) rc = e; }
+    if (rc != GNN_OK) return rc;
+    for (int r = 0; r < n; r++) d->rep[r]->time++;
     return GNN_OK;
 }
 
@@ -189,6 +195,18 @@ int dp_direct_begin(gnn_mlp_dp *d, int r) {
 }
 
 int dp_check(const gnn_mlp_dp *d) { return d ? GNN_OK : fail(GNN_ERR_BAD_ARG, "null handle"); }
+int dp_check_steppable(const gnn_mlp_dp *d) {
+    TRY(dp_check(d));
+    if (d->broken) return fail(GNN_ERR_STATE, "an earlier data-parallel step failed part-way: the replicas may differ (gnn_mlp_dp_replicas_identical); "
+                                              "destroy the handle, or restore every replica from a checkpoint and call gnn_mlp_dp_set_weights");
+    return GNN_OK;
+}
+// runs a step's body; a failure once work may have been enqueued on some replica leaves the handle marked
+template <class F> int dp_guard_step(gnn_mlp_dp *d, F &&body) {
+    const int rc = body();
+    if (rc != GNN_OK) d->broken = true;
+    return rc;
+}
 
 } // namespace
 
@@ -299,25 +317,27 @@ int gnn_mlp_dp_replica(gnn_mlp_dp_t *d, int r, gnn_mlp_t **out) { return guarded
 }); }
 
 int gnn_mlp_dp_gradient_step(gnn_mlp_dp_t *d, const double *X, const double *Y, int B, double step, double momentum, int noise) { return guarded([&]() -> int {
-    TRY(dp_check(d));
+    TRY(dp_check_steppable(d));
     if (!X || !Y) return fail(GNN_ERR_BAD_ARG, "null argument (reference: assert batch != null, SCE:299)");
     if (B <= 0) return fail(GNN_ERR_BAD_ARG, "batch must be non-empty (SCE:300)");
     if (B > d->max_batch) return fail(GNN_ERR_BAD_ARG, "B exceeds max_batch given to gnn_mlp_dp_create");
     if (noise) return fail(GNN_ERR_UNSUPPORTED, "noise=true is not built on the GPU (SCE:335)");
     if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
     const int d0 = d->rep[0]->dims[0], dl = d->rep[0]->dims[d->rep[0]->L - 1];
-    for (int r = 0; r < d->n; r++) {
-        int lo, hi;
-        dp_shard(B, r, d->n, &lo, &hi);
-        gnn_mlp *h = d->rep[r];
-        TRY(check_handle(h));
-        if (d->reducer != GNN_REDUCE_RCCL) TRY(dp_direct_begin(d, r));
-        if (hi > lo) TRY(gnn_mlp_compute_gradient(h, X + (size_t)lo * d0, Y + (size_t)lo * dl, hi - lo));
-        else HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * (size_t)h->n_pad, h->stream)); // no rows: a zero partial gradient
-    }
-    TRY(dp_reduce_and_update(d, B, step, momentum));
-    d->steps++;
-    return GNN_OK;
+    return dp_guard_step(d, [&]() -> int {
+        for (int r = 0; r < d->n; r++) {
+            int lo, hi;
+            dp_shard(B, r, d->n, &lo, &hi);
+            gnn_mlp *h = d->rep[r];
+            TRY(check_handle(h));
+            if (d->reducer != GNN_REDUCE_RCCL) TRY(dp_direct_begin(d, r));
+            if (hi > lo) TRY(gnn_mlp_compute_gradient(h, X + (size_t)lo * d0, Y + (size_t)lo * dl, hi - lo));
+            else HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * (size_t)h->n_pad, h->stream)); // no rows: a zero partial gradient
+        }
+        TRY(dp_reduce_and_update(d, B, step, momentum));
+        d->steps++;
+        return GNN_OK;
+    });
 }); }
 
 int gnn_mlp_dp_upload_dataset(gnn_mlp_dp_t *d, const double *X, const double *Y, int64_t N) { return guarded([&]() -> int {
@@ -326,7 +346,11 @@ int gnn_mlp_dp_upload_dataset(gnn_mlp_dp_t *d, const double *X, const double *Y,
     return GNN_OK;
 }); }
 
+static int dp_step_range_body(gnn_mlp_dp *d, int64_t first, int B, double step, double momentum, int64_t next_first);
 static int dp_step_range(gnn_mlp_dp *d, int64_t first, int B, double step, double momentum, int64_t next_first) {
+    return dp_guard_step(d, [&]() -> int { return dp_step_range_body(d, first, B, step, momentum, next_first); });
+}
+static int dp_step_range_body(gnn_mlp_dp *d, int64_t first, int B, double step, double momentum, int64_t next_first) {
     for (int r = 0; r < d->n; r++) {
         int lo, hi;
         dp_shard(B, r, d->n, &lo, &hi);
@@ -343,7 +367,7 @@ static int dp_step_range(gnn_mlp_dp *d, int64_t first, int B, double step, doubl
 }
 
 int gnn_mlp_dp_gradient_step_range(gnn_mlp_dp_t *d, int64_t first, int B, double step, double momentum, int noise) { return guarded([&]() -> int {
-    TRY(dp_check(d));
+    TRY(dp_check_steppable(d));
     if (B <= 0 || B > d->max_batch) return fail(GNN_ERR_BAD_ARG, "B out of range");
     if (noise) return fail(GNN_ERR_UNSUPPORTED, "noise=true is not built on the GPU (SCE:335)");
     if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
@@ -352,7 +376,7 @@ int gnn_mlp_dp_gradient_step_range(gnn_mlp_dp_t *d, int64_t first, int B, double
 }); }
 
 int gnn_mlp_dp_train_range(gnn_mlp_dp_t *d, int64_t first, int B, int n_steps, double step, double momentum) { return guarded([&]() -> int {
-    TRY(dp_check(d));
+    TRY(dp_check_steppable(d));
     if (B <= 0 || B > d->max_batch) return fail(GNN_ERR_BAD_ARG, "B out of range");
     if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
     if (n_steps <= 0) return fail(GNN_ERR_BAD_ARG, "n_steps must be positive (NNT:62)");
@@ -360,7 +384,9 @@ int gnn_mlp_dp_train_range(gnn_mlp_dp_t *d, int64_t first, int B, int n_steps, d
     if (nb <= 0 || first < 0 || first % B != 0) return fail(GNN_ERR_BAD_ARG, "first must be a multiple of B inside the dataset");
     for (int s = 0; s < n_steps; s++) {
         const int64_t row0 = ((first / B + s) % nb) * B;
-        const int64_t nxt = (s + 1 < n_steps) ? ((first / B + s + 1) % nb) * B : -1;
+        // (the LAST step names the batch that follows the range in the data set, as gnn_mlp_train_range does: calls that walk the
+        //  data set one after the other then continue one chain of two-launch steps)
+        const int64_t nxt = ((first / B + s + 1) % nb) * B;
         TRY(dp_step_range(d, row0, B, step, momentum, nxt));
     }
     return GNN_OK;

@@ -13,7 +13,14 @@ using namespace gnn;
 using namespace gnn::host;
 
 // The k-th set bit (k 0-based, k < popcount) of a 64-bit word: deposit one bit at the k-th set position, count the zeros below it.
+#if defined(__x86_64__)
 __attribute__((target("bmi2"))) static inline int select_bit_bmi2(uint64_t w, int k) { return (int)__builtin_ctzll(__builtin_ia32_pdep_di(1ull << k, w)); }
+static inline bool have_bmi2() { return __builtin_cpu_supports("bmi2"); }
+#else
+static inline int select_bit_plain(uint64_t w, int k);
+static inline int select_bit_bmi2(uint64_t w, int k) { return select_bit_plain(w, k); }
+static inline bool have_bmi2() { return false; }
+#endif
 static inline int select_bit_plain(uint64_t w, int k) {
     for (; k > 0; k--) w &= w - 1;
     return (int)__builtin_ctzll(w);
@@ -72,7 +79,7 @@ int gnn_sampler_create(int32_t master_size, int64_t seed, gnn_sampler_t **out) {
     s->words = (master_size + 63) / 64;
     s->rnd.set_seed(seed);
     while ((1 << (s->log2w + 1)) <= s->words) s->log2w++;
-    s->bmi2 = __builtin_cpu_supports("bmi2");
+    s->bmi2 = have_bmi2();
     s->refill();
     *out = s;
     return GNN_OK;
