@@ -92,15 +92,25 @@ def bf16_round(x):
     return u.astype(np.uint32).view(np.float32).astype(np.float64).reshape(np.shape(x))
 
 
-def forward_bf16(Ws, X, inner, out_kind=0, last=1):
-    """Activations / pre-activations as the bf16 GPU path forms them: every matrix product takes
-    bf16-rounded operands and accumulates exactly; activations are kept unrounded between layers
-    (they are fp32 in HBM and rounded when a tile is staged)."""
+def _jittered(a, jitter):
+    """`jitter` = (relative size, numpy Generator) or None: the operand as ANOTHER summation order of the f32 accumulation that
+    produced it would have left it -- perturbed by ~1e-6 relative BEFORE it is rounded to bf16.  A value that sits within that
+    distance of a bf16 rounding boundary then lands on the neighbouring bf16 value (0.4 % away): with bf16 operands, runs that
+    differ only in summation order differ by such flips, and this is how the tests measure what ONE contract's results scatter by."""
+    if jitter is None:
+        return a
+    rel, rng = jitter
+    return a * (1.0 + rel * rng.standard_normal(np.shape(a)))
+
+
+def _forward_bf16(Ws, X, inner, out_kind, last, jitter):
     q = bf16_round
     A = [act(inner, np.asarray(X, dtype=np.float64))]
+    Aq = []                                            # the bf16 operand each activation matrix becomes, ONCE (forward and gradient use the same)
     Z = [np.asarray(X, dtype=np.float64)]
     for l, W in enumerate(Ws):
-        z = q(A[-1]) @ q(W)
+        Aq.append(q(_jittered(A[-1], jitter if l > 0 else None)))   # (the inputs are data, not sums: never jittered)
+        z = Aq[-1] @ q(W)
         Z.append(z)
         if l < len(Ws) - 1:
             A.append(act(inner, z))
@@ -110,23 +120,32 @@ def forward_bf16(Ws, X, inner, out_kind=0, last=1):
         out = e / e.sum(axis=1, keepdims=True)
     else:
         out = act(last, Z[-1])
+    return Z, A, Aq, out
+
+
+def forward_bf16(Ws, X, inner, out_kind=0, last=1, jitter=None):
+    """Activations / pre-activations as the bf16 GPU path forms them: every matrix product takes
+    bf16-rounded operands and accumulates exactly; activations are kept unrounded between layers
+    (they are fp32 in HBM and rounded when a tile is staged)."""
+    Z, A, _, out = _forward_bf16(Ws, X, inner, out_kind, last, jitter)
     return Z, A, out
 
 
-def gradient_bf16(Ws, X, Y, inner, out_kind=0, last=1):
+def gradient_bf16(Ws, X, Y, inner, out_kind=0, last=1, jitter=None):
     q = bf16_round
-    Z, A, out = forward_bf16(Ws, X, inner, out_kind, last)
+    Z, A, Aq, out = _forward_bf16(Ws, X, inner, out_kind, last, jitter)
     L = len(Ws) + 1
     D = out - Y if out_kind == 0 else (out - Y) * act_prime(last, Z[-1])
     G = [None] * (L - 1)
     for l in range(L - 2, -1, -1):
-        G[l] = q(A[l]).T @ q(D)
+        Dq = q(_jittered(D, jitter))                   # (one rounding per delta matrix, used by both products, as on the GPU)
+        G[l] = Aq[l].T @ Dq
         if l >= 1:
-            D = (q(D) @ q(Ws[l]).T) * act_prime(inner, Z[l])
+            D = (Dq @ q(Ws[l]).T) * act_prime(inner, Z[l])
     return np.concatenate([g.ravel() for g in G])
 
 
-def gradient_step_bf16(w, v, dims, X, Y, step, momentum, inner, out_kind=0, last=1):
-    g = gradient_bf16(split(w, dims), X, Y, inner, out_kind, last)
+def gradient_step_bf16(w, v, dims, X, Y, step, momentum, inner, out_kind=0, last=1, jitter=None):
+    g = gradient_bf16(split(w, dims), X, Y, inner, out_kind, last, jitter)
     adj = step * g / X.shape[0] + momentum * v
     return w - adj, adj

@@ -131,13 +131,27 @@ def test_bf16_rowblock_kernel_against_middle4(gnn, monkeypatch, dims, B, inner):
     new.upload_dataset(X, Y); old.upload_dataset(X, Y)
     new.train_range(0, B, n, 0.0125, 0.9)
     old.train_range(0, B, n, 0.0125, 0.9)
-    assert np.abs(new.get_weights() - old.get_weights()).max() <= 8e-4   # (each is within 5e-4 of the oracle, below)
-    w, v = w0.copy(), np.zeros_like(w0)
     X32 = X.astype(np.float32).astype(np.float64)
-    for s in range(n):
-        sl = slice((s % nb) * B, (s % nb + 1) * B)
-        w, v = np_oracle.gradient_step_bf16(w, v, dims, X32[sl], Y[sl], 0.0125, 0.9, inner)
-    # (a handful of weights sit a bf16 step of some activation away from the fp64-accumulated oracle: 3.3e-4 at most here)
-    assert np.abs(new.get_weights() - w).max() <= 5e-4
-    assert np.abs(old.get_weights() - w).max() <= 5e-4
+
+    def oracle_run(jitter):
+        w, v = w0.copy(), np.zeros_like(w0)
+        for s in range(n):
+            sl = slice((s % nb) * B, (s % nb + 1) * B)
+            w, v = np_oracle.gradient_step_bf16(w, v, dims, X32[sl], Y[sl], 0.0125, 0.9, inner, jitter=jitter)
+        return w
+    w = oracle_run(None)
+    # How far may a correct kernel be from the oracle?  NOT "a few f32 ulps": with bf16 operands two evaluations of the same
+    # contract that differ only in the summation order of an f32 accumulation differ wherever an activation or a delta sits within
+    # ~1e-6 (relative) of a bf16 rounding boundary -- it then lands on the neighbouring bf16 value, 0.4 % away; with activations of
+    # 20..75 behind weights of 0.5 that moves a logit by ~0.1, that sample's output delta by percents, and through a_l^T delta a
+    # whole rank-one slice of every layer's gradient.  The bound is therefore MEASURED on the oracle itself: the same three steps
+    # with every rounded operand perturbed by 1e-6 before it is rounded (np_oracle._jittered), four seeds.  At 784-300-100-10 /
+    # B = 128 (~51 000 activations per step, ~25 of them expected within reach of a boundary) the oracle's own runs end up
+    # 3.4e-4 / 7.6e-5 / 8.0e-5 / 5.5e-5 from the unperturbed one -- round 3 saw 3.3e-4 on the GPU there and widened a fixed 3e-4
+    # to 5e-4 without saying why: this is why -- and 9e-6 / 4e-7 / 3e-6 at the three small shapes, where the floor of 1e-4 applies.
+    scatter = max(np.abs(oracle_run((1e-6, np.random.default_rng(k))) - w).max() for k in range(1, 5))
+    bound = max(2.0 * scatter, 1e-4)
+    assert np.abs(new.get_weights() - w).max() <= bound, (scatter, bound)
+    assert np.abs(old.get_weights() - w).max() <= bound, (scatter, bound)
+    assert np.abs(new.get_weights() - old.get_weights()).max() <= 2 * bound   # (each is within `bound` of the oracle)
     assert np.mean(np.abs(new.get_weights() - w)) <= 2e-5
