@@ -422,57 +422,73 @@ static __global__ __launch_bounds__(256) void output_layer_kernel(OutParams p) {
     // at index 0 is sticky (label 0) while a NaN elsewhere is never selected.  With softmax any
     // NaN logit makes EVERY probability NaN, i.e. label 0.
     bool has_nan = false;
-    constexpr int CV = 16; // a row of up to 64*CV logits is held in registers: ONE round trip to memory
-    if (p.out_kind == 0 && p.n_pad <= 64 * CV) {
-        // (a row read three times with dependent loads -- max, sum, probabilities -- cost 19.6 us at 512 x 1024)
-        const int nv = (p.n_pad + 63) / 64; // wave-uniform
-        float zc[CV], yc[CV];
+    constexpr int CV = 4; // a row of up to 256*CV logits is held in registers: ONE round trip to memory
+    if (p.out_kind == 0 && p.n_pad <= 256 * CV) {
+        // (a row read three times with dependent loads -- max, sum, probabilities -- cost 19.6 us at 512 x 1024; with one 4-B access
+        //  per lane and column the 512 x 1024 rows of configs[3] took 6.6 us, mostly 4-B stores at ~7 B/clk/CU: a lane now owns FOUR
+        //  consecutive columns per 256-column chunk -- 16-B loads and stores; leading dimensions are multiples of 16 floats)
+        const int nv = (p.n_pad + 255) / 256; // wave-uniform
+        f32x4 zc[CV], yc[CV];
 #pragma unroll
         for (int i = 0; i < CV; i++) {
-            const int c = lane + 64 * i;
-            zc[i] = 0.f; yc[i] = 0.f;
+            const int c = 4 * lane + 256 * i;
+            zc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; yc[i] = zc[i];
             if (i < nv && c < p.n_pad) {
-                zc[i] = z[c];
-                if (y) yc[i] = y[c];
+                zc[i] = *reinterpret_cast<const f32x4 *>(z + c);
+                if (y) yc[i] = *reinterpret_cast<const f32x4 *>(y + c);
             }
         }
         float mx = -__builtin_inff();
         int best = -1;
 #pragma unroll
-        for (int i = 0; i < CV; i++) {
-            const int c = lane + 64 * i;
-            if (i < nv && c < p.n_true) {
-                has_nan |= (zc[i] != zc[i]);
-                if (zc[i] >= mx) { mx = zc[i]; best = c; } // ascending c within a lane: `>=` keeps the highest
+        for (int i = 0; i < CV; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = 4 * lane + 256 * i + j;
+                const float v = zc[i][j];
+                if (i < nv && c < p.n_true) {
+                    has_nan |= (v != v);
+                    if (v >= mx) { mx = v; best = c; } // ascending c within a lane: `>=` keeps the highest
+                }
             }
-        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { // larger value wins, equal values -> higher index (MT:166-168)
             const float ov = __shfl_xor(mx, o);
             const int ob = __shfl_xor(best, o);
             if (ov > mx || (ov == mx && ob > best)) { mx = ov; best = ob; }
         }
-        float s = 0.f, e[CV];
+        float s = 0.f;
+        f32x4 e[CV];
 #pragma unroll
-        for (int i = 0; i < CV; i++) {
-            e[i] = 0.f;
-            if (i < nv && lane + 64 * i < p.n_true) { e[i] = __expf(zc[i] - mx); s += e[i]; }
-        }
+        for (int i = 0; i < CV; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float ev = (i < nv && 4 * lane + 256 * i + j < p.n_true) ? __expf(zc[i][j] - mx) : 0.f;
+                e[i][j] = ev; s += ev;
+            }
         s = wave_sum(s);
         const float inv = 1.f / s;
         const float lse = mx + __logf(s);
         float l = 0.f;
 #pragma unroll
         for (int i = 0; i < CV; i++) {
-            const int c = lane + 64 * i;
+            const int c = 4 * lane + 256 * i;
             if (i < nv && c < p.n_pad) {
-                const bool live = live_row && c < p.n_true;
-                const float pr = live ? e[i] * inv : 0.f;
-                const float yy = live ? yc[i] : 0.f;
-                if (p.prob) p.prob[(size_t)row * p.ldp + c] = pr;
-                if (p.delta) p.delta[(size_t)row * p.ldd + c] = live ? pr - yy : 0.f;
-                if (p.delta_b) p.delta_b[(size_t)row * p.ldd + c] = (__bf16)(live ? pr - yy : 0.f);
-                if (live && yy != 0.f) l += yy * (lse - zc[i]); // -y ln p
+                f32x4 pr, dd;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool live = live_row && c + j < p.n_true;
+                    pr[j] = live ? e[i][j] * inv : 0.f;
+                    const float yy = live ? yc[i][j] : 0.f;
+                    dd[j] = live ? pr[j] - yy : 0.f;
+                    if (live && yy != 0.f) l += yy * (lse - zc[i][j]); // -y ln p
+                }
+                if (p.prob) *reinterpret_cast<f32x4 *>(p.prob + (size_t)row * p.ldp + c) = pr;
+                if (p.delta) *reinterpret_cast<f32x4 *>(p.delta + (size_t)row * p.ldd + c) = dd;
+                if (p.delta_b) {
+                    typedef __bf16 out_bf16x4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<out_bf16x4 *>(p.delta_b + (size_t)row * p.ldd + c) = (out_bf16x4){(__bf16)dd[0], (__bf16)dd[1], (__bf16)dd[2], (__bf16)dd[3]};
+                }
             }
         }
         l = wave_sum(l);

@@ -31,6 +31,14 @@ void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
     // keep more of it in flight: 4096 x 2048 x 512 with the update 41.5 us on 128 x 128 tiles (one workgroup per CU at its
     // register count), 32.4 us on 64 x 64 (profiles/r02/gemm_probe_bf16_interior.log)
     if (tile == 128 && !A_KC && !B_KC && EPI == EPI_SGD) tile = 64;
+    // a forward product whose 64 x 64 grid is 128..255 tiles (the 512 x 1024 logits of configs[3]: 128) leaves half the chip
+    // without a workgroup: 32 x 64 tiles, twice as many, 13.2 -> 10.1 us there.  Every other shape tried in round 4 -- 64 x 32,
+    // 32 x 64, 32 x 32, 128 x 64 on the backward-data, forward-2 and gradient + update products -- is 5-45 % SLOWER than the
+    // shipped 64 x 64 (profiles/r04/gemm_probe_bf16_tile_shapes.log).
+    if constexpr (A_KC && !B_KC) {
+        const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
+        if (tile == 64 && t64 < 256 && p.M % 32 == 0) { launch_gemm_bf16_t<32, 64, A_KC, B_KC, EPI>(h, cls, p); return; }
+    }
     switch (tile) {
     case 128: launch_gemm_bf16_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;
     case 64:

@@ -180,6 +180,33 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (which == 30) {
+        printf("---- round 4: bf16 tile shapes on the products of configs[3] that run few or memory-bound workgroups (each twice)\n");
+        for (int rep = 0; rep < 2; rep++) {
+            runb<64, 64, true, false, EPI_STORE, 2, 4>("logits (shipped)", 512, 1024, 2048);
+            runb<64, 32, true, false, EPI_STORE, 2, 2>("logits", 512, 1024, 2048);
+            runb<64, 32, true, false, EPI_STORE, 2, 4>("logits", 512, 1024, 2048);
+            runb<32, 64, true, false, EPI_STORE, 2, 2>("logits", 512, 1024, 2048);
+            runb<32, 32, true, false, EPI_STORE, 2, 2>("logits", 512, 1024, 2048);
+            runb<64, 64, true, true, EPI_DACT, 2, 2>("backward data 2 (shipped)", 512, 2048, 1024);
+            runb<64, 32, true, true, EPI_DACT, 2, 2>("backward data 2", 512, 2048, 1024);
+            runb<32, 64, true, true, EPI_DACT, 2, 2>("backward data 2", 512, 2048, 1024);
+            runb<64, 64, true, true, EPI_DACT, 2, 2>("backward data 1 (shipped)", 512, 2048, 2048);
+            runb<64, 32, true, true, EPI_DACT, 2, 2>("backward data 1", 512, 2048, 2048);
+            runb<64, 64, true, false, EPI_ACT, 2, 4>("forward 2 (shipped)", 512, 2048, 2048);
+            runb<64, 32, true, false, EPI_ACT, 2, 4>("forward 2", 512, 2048, 2048);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 0 (shipped)", 4096, 2048, 512);
+            runb<64, 32, false, false, EPI_SGD, 2, 2>("gradient + update 0", 4096, 2048, 512);
+            runb<32, 64, false, false, EPI_SGD, 2, 2>("gradient + update 0", 4096, 2048, 512);
+            runb<128, 64, false, false, EPI_SGD, 2, 2>("gradient + update 0", 4096, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 1 (shipped)", 2048, 2048, 512);
+            runb<64, 32, false, false, EPI_SGD, 2, 2>("gradient + update 1", 2048, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 2 (shipped)", 2048, 1024, 512);
+            runb<64, 32, false, false, EPI_SGD, 2, 2>("gradient + update 2", 2048, 1024, 512);
+            runb<32, 32, false, false, EPI_SGD, 2, 2>("gradient + update 2", 2048, 1024, 512);
+        }
+        return 0;
+    }
     if (which == 21) {
         printf("---- wave-K kernel: main-loop arguments preloaded (head) against read from the struct (each pair three times)\n");
         for (int rep = 0; rep < 3; rep++) {
