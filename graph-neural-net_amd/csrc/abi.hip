@@ -29,6 +29,7 @@ void read_env(gnn_mlp *h) {
     h->env_chain_off = is("GNN_MLP_CHAIN", "0");
     h->env_wavek_off = is("GNN_MLP_WAVEK", "0");
     h->env_rb_off = is("GNN_MLP_ROWBLOCK", "0");
+    h->env_defer_off = is("GNN_MLP_DEFER", "0");
     const char *fg = getenv("GNN_MLP_FIRST_GEMM_ROWS"); // development: from how many rows on the first layer runs as a tiled GEMM (0 = never)
     if (fg) h->first_gemm_rows = atoi(fg);
 }
@@ -62,10 +63,12 @@ int check_launches(gnn_mlp *h) {
     return GNN_OK;
 }
 
-int check_handle(const gnn_mlp *h) {
+int check_handle(gnn_mlp *h, bool apply_pending) {
     if (!h) return fail(GNN_ERR_BAD_ARG, "null handle");
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return fail(GNN_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    // a host-batch step whose update waits for the next call's tile launch: any OTHER entry point sees the updated weights
+    if (apply_pending && h->pend.on) flush_pending_update(h);
     return GNN_OK;
 }
 
@@ -191,6 +194,7 @@ int gnn_mlp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act,
     const size_t rows = (size_t)h->cap_rows;
     for (int l = 0; l < n_dims - 1; l++) CTRY(dev_alloc(&h->act[l], rows * h->ld[l], h->stream));
     for (int l = 1; l < n_dims; l++) CTRY(dev_alloc(&h->delta[l], rows * h->ld[l], h->stream));
+    if (dtype == GNN_DTYPE_F32) CTRY(dev_alloc(&h->act0_alt, rows * h->ld[0], h->stream)); // (host batches with a deferred update: handle.h)
     const int ldo = h->ld[n_dims - 1];
     CTRY(dev_alloc(&h->logits, rows * ldo, h->stream));
     CTRY(dev_alloc(&h->prob, rows * ldo, h->stream));
@@ -233,7 +237,7 @@ int gnn_mlp_destroy(gnn_mlp_t *h) { return guarded([&]() -> int {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
-    fr(h->W); fr(h->V); fr(h->G_own);
+    fr(h->W); fr(h->V); fr(h->G_own); fr(h->act0_alt);
     for (float *p : h->act) fr(p);
     for (float *p : h->delta) fr(p);
     fr(h->logits); fr(h->prob); fr(h->ybuf); fr(h->lossv); fr(h->labels); fr(h->idxbuf);
@@ -321,11 +325,20 @@ int gnn_mlp_weight_gradient(gnn_mlp_t *h, const double *X, const double *Y, int 
 
 int gnn_mlp_gradient_step(gnn_mlp_t *h, const double *X, const double *Y, int B, double step, double momentum,
                           int noise) { return guarded([&]() -> int {
-    TRY(check_handle(h));
-    if (!X || !Y) return fail(GNN_ERR_BAD_ARG, "null argument (reference: assert batch != null, SCE:299)");
-    TRY(check_batch(h, B));
-    if (noise) return fail(GNN_ERR_UNSUPPORTED, "noise=true is NaN-producing in the reference (SCE:335 sqrt of a negative draw) and is not built on the GPU");
-    if (!(step > 0)) return fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
+    TRY(check_handle(h, false)); // (a pending update is taken up by THIS call's tile launch, below)
+    int rc = GNN_OK;
+    if (!X || !Y) rc = fail(GNN_ERR_BAD_ARG, "null argument (reference: assert batch != null, SCE:299)");
+    if (rc == GNN_OK) rc = check_batch(h, B);
+    if (rc == GNN_OK && noise) rc = fail(GNN_ERR_UNSUPPORTED, "noise=true is NaN-producing in the reference (SCE:335 sqrt of a negative draw) and is not built on the GPU");
+    if (rc == GNN_OK && !(step > 0)) rc = fail(GNN_ERR_BAD_ARG, "step must be positive (SCE:301)");
+    if (rc != GNN_OK) { flush_pending_update(h); return rc; } // (a refused call leaves nothing pending either)
+    if (can_defer_update(h)) {
+        // the new batch goes to the OTHER A_0 buffer: the pending step's gradient still reads its own
+        if (h->pend.on) std::swap(h->act[0], h->act0_alt);
+        rc = stage_batch(h, X, Y, B);   // the caller's rows are not read after this returns
+        if (rc != GNN_OK) { if (h->pend.on) std::swap(h->act[0], h->act0_alt); flush_pending_update(h); return rc; }
+        return step_on_host_batch_deferred(h, B, step, momentum);
+    }
     TRY(stage_batch(h, X, Y, B));   // the caller's rows are not read after this returns
     h->have_next = false; // (a hint refers to dataset rows; this batch came from the host)
     return step_on_rows(h, h->act[0], h->ybuf, B, step, momentum, false);

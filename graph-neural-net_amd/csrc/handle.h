@@ -112,6 +112,15 @@ struct gnn_mlp {
     int64_t tr_first_batch = -1; int tr_B = 0; int64_t tr_nb = 0; double tr_step = 0, tr_mom = 0;
     const float *tr_dx = nullptr;
 
+    // Host batches on the two-launch path (gnn_mlp_gradient_step, the reference's own call shape NNT:83): the UPDATE of a step is
+    // deferred into the next call's tile launch, which then also forms the new batch's first-layer sums from the weights it has
+    // just written -- three dependent launches per call (staging, tile, row-block) instead of four.  `pend` describes the step
+    // whose gradient operands (A_0 in act[0], A_l / delta_l in their buffers) wait for that launch; every other entry point
+    // applies it first (check_handle).  act0_alt: the second A_0 buffer (the next batch is staged while the pending one is read).
+    struct PendingUpdate { bool on = false; int B = 0; float step_over_b = 0.f, momentum = 0.f; } pend;
+    float *act0_alt = nullptr;
+    bool env_defer_off = false;  // GNN_MLP_DEFER=0: the update in the call that computed it (four launches; development)
+
     hipError_t launch_error = hipSuccess; // first refused launch of a module / function-pointer kernel since the last check
     const int32_t *cur_idx = nullptr; // device row indices of the batch being stepped (fused path reads rows through them)
 
@@ -138,7 +147,7 @@ namespace host {
 int fail(int code, const std::string &msg);   // records the calling thread's message, returns `code`
 const char *last_error_message();
 int check_launches(gnn_mlp *h);
-int check_handle(const gnn_mlp *h);
+int check_handle(gnn_mlp *h, bool apply_pending = true); // (apply_pending: a host-batch step's deferred update runs first, plan.hip)
 int check_batch(const gnn_mlp *h, int B);
 int check_range(const gnn_mlp *h, int64_t first, int B);
 int check_step_args(gnn_mlp *h, int B, double step, int noise);
@@ -302,6 +311,9 @@ void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_pr
 void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum,
                  bool resident = false);
 void maybe_specialize(gnn_mlp *h);
+bool can_defer_update(const gnn_mlp *h);
+int step_on_host_batch_deferred(gnn_mlp *h, int B, double step, double momentum); // act[0] / ybuf hold the staged batch
+void flush_pending_update(gnn_mlp *h);
 int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step, double momentum, bool resident);
 int step_on_device_indices(gnn_mlp *h, const int32_t *d_idx, int B, double step, double momentum);
 

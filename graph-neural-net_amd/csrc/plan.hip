@@ -309,6 +309,49 @@ int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step
     return GNN_OK;
 }
 
+// ---- host batches with the update deferred into the next call (handle.h: PendingUpdate) ----------------------------------
+// f32 nets on the two-launch path, outside stream capture (a captured sequence must be self-contained)
+bool can_defer_update(const gnn_mlp *h) {
+    if (!h->chain || h->dtype != GNN_DTYPE_F32 || !h->act0_alt || h->env_defer_off) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st == hipStreamCaptureStatusNone;
+}
+
+// The pending step's update by itself (tile_step_kernel<1, 2, false>): its gradient operands are where the row-block kernel
+// left them, its A_0 in act[0].
+void flush_pending_update(gnn_mlp *h) {
+    if (!h->pend.on) return;
+    h->pend.on = false;
+    h->cur_idx = nullptr;
+    launch_tile_step(h, 1, 2, nullptr, h->act[0], h->pend.B, h->pend.step_over_b, h->pend.momentum);
+    h->slab_valid = false; h->have_next = false; h->xstage_valid = false;
+}
+
+// One gradientStep on the batch staged in act[0] / ybuf: (update of the PENDING step + this batch's first-layer sums) in one
+// tile launch -- or the chain's forward-only launch when nothing is pending --, then the row-block kernel; this step's own
+// update stays pending.  The arithmetic is train_range's (tile_step_kernel<1, 2, true> between two row-block launches):
+// the same weights, bit for bit, as with the update in the call that computed it.
+int step_on_host_batch_deferred(gnn_mlp *h, int B, double step, double momentum) {
+    maybe_specialize(h);
+    const float *a0 = h->act[0];
+    h->cur_idx = nullptr;
+    h->have_next = false; // (a hint refers to dataset rows; this batch came from the host)
+    const NextBatch self{a0, nullptr, B};
+    if (h->pend.on) {
+        h->pend.on = false;
+        launch_tile_step(h, 1, 2, &self, h->act0_alt, h->pend.B, h->pend.step_over_b, h->pend.momentum);
+    } else {
+        launch_tile_step(h, 0, 0, &self, a0, B, 0.f, 0.f);
+    }
+    h->slab_valid = false; h->xstage_valid = false; // (a staging buffer holds other rows under the same address at the next call)
+    fused_forward(h, a0, h->ybuf, B, true, false, false, false, true, RB_COPY_NONE);
+    h->pend.on = true; h->pend.B = B; h->pend.step_over_b = (float)(step / (double)B); h->pend.momentum = (float)momentum;
+    h->time++;
+    TRY_LAUNCHES(h);
+    return GNN_OK;
+}
+
 // the next gradient computation runs on dataset rows [row0, row0 + B)
 void hint_range(gnn_mlp *h, int64_t row0, int B) {
     h->have_next = true; h->next_a0 = h->DX + (size_t)row0 * h->ld[0]; h->next_idx = nullptr; h->next_B = B;

@@ -111,7 +111,11 @@ int gnn_mlp_weight_gradient(gnn_mlp_t *h, const double *X, const double *Y, int 
 
 /* NN:51 gradientStep (SCE:297-346, GNN:317-366): G = sum over the batch of the per-sample
  * gradients; adj = step*G/B + momentum*prev; W -= adj; prev = adj; time++.
- * noise != 0 -> GNN_ERR_UNSUPPORTED.  Returns after enqueueing (asynchronous). */
+ * noise != 0 -> GNN_ERR_UNSUPPORTED.  Returns after enqueueing (asynchronous).  On the small-net path the weight UPDATE of a
+ * call is enqueued with the NEXT gradient_step call (one kernel then applies it and starts the new batch: three dependent
+ * launches per call instead of four), or by whichever other entry point of the handle is called first -- every entry point
+ * sees the updated weights, `time` counts the step at the call, results are the same bit for bit (GNN_MLP_DEFER=0 switches
+ * it off). */
 int gnn_mlp_gradient_step(gnn_mlp_t *h, const double *X, const double *Y, int B, double step,
                           double momentum, int noise);
 

@@ -913,3 +913,50 @@ def test_full_size_leaky_relu_whole_batch(gnn, dims, B, scale):
     tol = 0.0125 / B * 5e-5 * max(np.abs(x).max() for x in g.values()) + 2e-7 * np.abs(w).max() + 1e-9
     assert np.abs(net.get_momentum() - v_ref).max() <= tol
     assert np.abs(net.get_weights() - w_ref).max() <= tol
+
+
+def test_host_batch_steps_with_the_update_deferred(gnn, oracle_mod, monkeypatch):
+    """NeuralNet.gradientStep(double[] rows) (NNT:83) on the two-launch path: each call's UPDATE rides in the next call's tile
+    launch (three dependent launches per call instead of four), and every other entry point applies a pending update first.
+    Against GNN_MLP_DEFER=0 (the update in the call that computed it): the SAME weights bit for bit, whatever is called in
+    between -- get_weights, propagate, calculateLoss, a ragged batch, a step on resident rows, a checkpoint --, `time` counted
+    at the call, and the oracle."""
+    import os
+    if os.environ.get("GNN_MLP_PATH") or os.environ.get("GNN_MLP_CHAIN") == "0":
+        pytest.skip("path forced by the environment")
+    dims, B = [784, 300, 100, 10], 128
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    monkeypatch.setenv("GNN_MLP_DEFER", "0")
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    monkeypatch.delenv("GNN_MLP_DEFER")
+    ref = oracle_mod.OracleNet(dims)
+    ref.set_alloc_per_sample(0)
+    Xd, Yd = make_batch(dims, 2 * B, seed=300, sparse=True)
+    a.upload_dataset(Xd, Yd); b.upload_dataset(Xd, Yd)
+    steps = 0
+    for k in range(12):
+        Bk = B if k % 5 else 77                      # ragged batches in between
+        X, Y = make_batch(dims, Bk, seed=310 + k, sparse=(k % 2 == 0))
+        a.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+        b.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+        ref.gradient_step(X, Y, 0.0125, 0.9)
+        steps += 1
+        assert a.time == steps == b.time             # counted at the call, pending or not
+        if k == 2:                                   # a read between two steps
+            assert np.array_equal(a.get_weights(), b.get_weights())
+        if k == 4:                                   # forward passes in between (they overwrite the activation buffers)
+            assert np.array_equal(a.propagate(X[:5]), b.propagate(X[:5]))
+            assert np.array_equal(a.calculateLoss(X[:5], Y[:5]), b.calculateLoss(X[:5], Y[:5]))
+        if k == 6:                                   # a step on resident rows in between
+            a.gradient_step_range(B, B, 0.0125, 0.9); b.gradient_step_range(B, B, 0.0125, 0.9)
+            ref.gradient_step(Xd[B:], Yd[B:], 0.0125, 0.9)
+            steps += 1
+        if k == 8:                                   # a refused call must not lose the pending update
+            with pytest.raises(gnn.GnnError):
+                a.gradientStep(X, -1.0, 0.9, False, expected=Y)
+            with pytest.raises(gnn.GnnError):
+                b.gradientStep(X, -1.0, 0.9, False, expected=Y)
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    assert np.array_equal(a.get_momentum(), b.get_momentum())
+    assert np.abs(a.get_weights() - ref.get_weights()).max() <= W_ATOL * steps
+    assert np.abs(a.get_momentum() - ref.get_momentum()).max() <= W_ATOL * steps
