@@ -690,6 +690,14 @@ def worker(args, argv):
     import torch
     import gnn_amd
 
+    # The interpreter's cyclic collector: with torch imported a full (generation-2) pass walks ~10^6 import-time objects and
+    # takes ~40 ms -- once, somewhere inside the per-call loops below (the host-batch loop of 1 000 calls read 70 us per call
+    # instead of 27 whenever it caught it: tools/_build/hp_variants.py, profiles/r04/host_path_gc_pause.log).  The objects
+    # alive now are moved to the permanent generation; the timed K steps are ONE library call and were never affected.
+    import gc
+    gc.collect()
+    gc.freeze()
+
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if args.share_gpu:
@@ -825,8 +833,8 @@ def worker(args, argv):
         if dist is None and headline_shape and not args.variant_child:
             # PCIe-inclusive rate of the literal NeuralNet.gradientStep(double[] rows) call shape: fp64 host
             # batch -> f32 in a pinned slot -> staging kernel reading it over PCIe -> step.  Reported beside `value`, never as `value`.
-            nh = 200
-            for s in range(20):
+            nh = 1000   # (~30 ms: the conversion helpers and the pinned slots are in their steady state after the first few dozen calls)
+            for s in range(50):
                 net.gradientStep(X[:BATCH], STEP, MOMENTUM, False, expected=Y[:BATCH])
             net.synchronize()
             th = time.perf_counter()

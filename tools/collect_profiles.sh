@@ -39,4 +39,8 @@ cp "$SRC/bench_three_launch.json" "$DST/final_bench_three_launch_GNN_MLP_CHAIN0.
 cp "$SRC/configs_all.jsonl"       "$DST/final_configs_all.jsonl"
 cp "$SRC/host_path.txt"           "$DST/final_host_path.txt"
 cp "$SRC/trainer.txt"             "$DST/final_trainer.txt"
+[ -f "$SRC/inference.jsonl" ] && cp "$SRC/inference.jsonl" "$DST/final_inference.jsonl"
+[ -f "$SRC/stats_inference/run_kernel_stats.csv" ] && cp "$SRC/stats_inference/run_kernel_stats.csv" "$DST/final_inference_kernel_stats.csv"
+[ -f "$SRC/bench_n2_rehearsal_two_ranks_sharing_one_gpu.json" ] && cp "$SRC/bench_n2_rehearsal_two_ranks_sharing_one_gpu.json" "$DST/"
+[ -f "$SRC/bench_default_after_profiling.json" ] && cp "$SRC/bench_default_after_profiling.json" "$DST/final_bench_f32_after_profiler_passes.json"
 ls -l "$DST" | head -60

@@ -47,4 +47,10 @@ tools/rowblock_probe > "$OUT/rowblock_probe.log" 2>&1
 tools/tile_probe > "$OUT/tile_probe.log" 2>&1
 for m in 0 1 2 3; do echo "GNN_MLP_HYBRID=$m"; GNN_MLP_HYBRID=$m python3 tools/bench_configs.py 5 f32 --steps 200 2>/dev/null; done > "$OUT/config5_hybrid_choices.jsonl"
 python3 tools/bench_trainer.py > "$OUT/trainer.txt" 2>&1
+# round 4: evaluation as one call (MT:181-197), the N > 1 record rehearsed with two ranks on this one GPU, the exchange primitive
+python3 tools/bench_configs.py inference 128 1024 4096 16384 > "$OUT/inference.jsonl" 2>&1
+( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_inference" -o run -- python3 $ROOT/tools/bench_configs.py inference 16384 > "$ROOT/$OUT/stats_inference.log" 2>&1 )
+python3 bench.py --gpus 2 --backend gloo --share-gpu --steps 256 --warmup 64 --no-cpu-baseline > "$OUT/bench_n2_rehearsal_two_ranks_sharing_one_gpu.json" 2> "$OUT/bench_n2_rehearsal.err"
+[ -x tools/_build/exchange_probe ] && tools/_build/exchange_probe 32 > "$OUT/exchange_probe.log" 2>&1
+[ -x tools/_build/rowblock_cluster_probe ] && tools/_build/rowblock_cluster_probe 128 > "$OUT/rowblock_cluster_probe.log" 2>&1
 ls -R "$OUT" | head -80
