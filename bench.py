@@ -57,8 +57,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 den
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF figure is 2:1 sparse)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 EXIT_CAPTURE_FAILED = 75       # a rank's stream capture did not produce a graph: rerun eager in fresh processes
-PMC_FILE = os.path.join("profiles", "r03", "pmc_traffic.json")
-MFMA_FILE = os.path.join("profiles", "r03", "mfma_counters.json")
+PMC_FILE = os.path.join("profiles", "r04", "pmc_traffic.json")
+MFMA_FILE = os.path.join("profiles", "r04", "mfma_counters.json")
 
 
 def parse_args(argv=None):

@@ -33,7 +33,13 @@ void launch_gemm_wavek(gnn_mlp *h, int cls, const GemmParams &p) {
 
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
-    const int tile = pick_tile(p.M, p.N);
+    int tile = pick_tile(p.M, p.N);
+    if (tile == 128) {
+        // a 128-wide tile grid that overhangs the output by much more than the 64-wide one does multiplies zeros: 16 384 x 304 (the
+        // first layer of 784-300-100-10 over an evaluation block) is 3 tile columns of 128 = 384 for 304 (79 %) against 5 of 64 = 320 (95 %)
+        auto eff = [&](int b) { return (double)p.M * p.N / ((double)((p.M + b - 1) / b * b) * ((p.N + b - 1) / b * b)); };
+        if (eff(64) > 1.1 * eff(128)) tile = 64;
+    }
     if (tile == 32 && !h->env_wavek_off && wavek_fits(p.M, p.N, p.K)) { launch_gemm_wavek<A_KC, B_KC, EPI>(h, cls, p); return; }
     // A square grid of 256..511 tiles is ONE 4-wave workgroup per CU: nothing covers its barriers and LDS latencies.  Measured
     // per form (profiles/r02/gemm_probe_tiles2.log, 512-row products of 4096-2048-2048-1024, one register stage, unguarded loads):
