@@ -399,21 +399,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         GNN_GU64_REQUEST(0);
         const float *ap = &As[(kh * (KC / 2) + fq) * LD + wm * 32 + fr * 2];
         const float *dp = &Ds[(kh * (KC / 2) + fq) * LD + wn * 32 + fr * 2];
-        auto multiply = [&]() { // this wave's half of the chunk
+        // this wave's half of the chunk in FOUR groups of eight k (two MFMA k steps, eight MFMAs); a group's operand fragments are
+        // read from LDS while the group before it multiplies (round 4: the compiler's order was read - wait - multiply per group,
+        // every group's LDS latency in front of its MFMAs: the ISA of profiles/r04/grad_update64_isa_before.txt)
+        auto multiply = [&]() {
+            constexpr int NG = KC / 2 / 8;
+            f32x2 a[2][2], d[2][2];
+            auto fetch = [&](int g, int buf) {
 #pragma unroll
-            for (int kk = 0; kk < KC / 2; kk += 16) {
-                f32x2 a[4], d[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    a[u] = *reinterpret_cast<const f32x2 *>(ap + (kk + 4 * u) * LD);
-                    d[u] = *reinterpret_cast<const f32x2 *>(dp + (kk + 4 * u) * LD);
+                for (int u = 0; u < 2; u++) {
+                    a[buf][u] = *reinterpret_cast<const f32x2 *>(ap + (8 * g + 4 * u) * LD);
+                    d[buf][u] = *reinterpret_cast<const f32x2 *>(dp + (8 * g + 4 * u) * LD);
                 }
+            };
+            fetch(0, 0);
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+            for (int g = 0; g < NG; g++) {
+                if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 2; u++)
 #pragma unroll
                     for (int i = 0; i < 2; i++)
 #pragma unroll
-                        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], d[u][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][u][i], d[g & 1][u][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         int k0 = 0;
