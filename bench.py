@@ -92,7 +92,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-dp-variants", action="store_true",
                     help="N > 1: only the headline (one process per GPU, RCCL); by default the same invocation also measures the "
                          "in-library reducers, bf16 configs[2], configs[4] and one GPU alone, each in fresh child processes")
-    ap.add_argument("--variant-timeout", type=float, default=240.0, help="seconds one dp variant may take before it is ended")
+    ap.add_argument("--variant-timeout", type=float, default=150.0, help="seconds one dp variant may take before it is ended")
+    ap.add_argument("--variants-budget", type=float, default=600.0,
+                    help="seconds all dp variants together may take: once spent, the remaining ones are skipped (reported as such)")
     ap.add_argument("--variant-child", action="store_true", help="(internal) this process measures ONE variant: no further children")
     args = ap.parse_args(argv)
     if args.no_graph:
@@ -279,21 +281,27 @@ def collect_variants(args):
     variant does can take the headline down."""
     import tempfile
     out = {}
+    t_begin = time.time()
     for name, kind, argv in dp_variant_specs(args):
         t0 = time.time()
+        left = args.variants_budget - (t0 - t_begin)
+        if left < 5.0:   # (a hung collective in one variant after the other must not hold the headline back for ever)
+            out[name] = {"error": "skipped: the variants' time budget of %.0f s is spent" % args.variants_budget}
+            continue
+        limit = min(args.variant_timeout, left)
         with tempfile.TemporaryFile(mode="w+") as errf:
             try:
                 if kind == "group":
-                    rc, text = run_group(argv, args.gpus, "eager", False, timeout=args.variant_timeout, stderr_to=errf)
+                    rc, text = run_group(argv, args.gpus, "eager", False, timeout=limit, stderr_to=errf)
                 else:
-                    rc, text = run_single(argv, args.variant_timeout, errf)
+                    rc, text = run_single(argv, limit, errf)
                 lines = [l for l in (text or "").splitlines() if l.strip().startswith("{")]
                 if rc == 0 and len(lines) == 1:
                     out[name] = summarize_variant(json.loads(lines[0]), time.time() - t0)
                     continue
                 errf.seek(0)
                 tail = [l for l in errf.read().splitlines() if l.strip()][-6:]
-                what = ("ended at the %.0f s limit" % args.variant_timeout) if rc == 124 else "exit code %d" % rc
+                what = ("ended at the %.0f s limit" % limit) if rc == 124 else "exit code %d" % rc
                 out[name] = {"error": what, "stderr_tail": [l[-300:] for l in tail], "child_wall_s": round(time.time() - t0, 1)}
             except Exception as e:   # (a variant must not take the headline down)
                 out[name] = {"error": "%s: %s" % (type(e).__name__, e)}

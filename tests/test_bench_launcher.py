@@ -126,7 +126,14 @@ def test_dp_variants_are_merged_and_a_failing_one_does_not_take_the_headline_dow
     assert c4["error"] == "exit code 3" and c4["stderr_tail"][-1] == "RuntimeError: rank 1 fell over"
     direct = next(v[n] for n in names if "library direct f32" in n)
     assert direct["value"] == 650.0 and direct["roofline"]["frac"] == 0.02 and direct["config"]["backend"] == "direct"
+    # once the variants' time budget is spent the rest is skipped, and says so
+    args = b.parse_args(["--gpus", "8", "--steps", "50", "--warmup", "10", "--variants-budget", "0"])
+    assert b.launch(args, ["--gpus", "8", "--steps", "50", "--warmup", "10", "--variants-budget", "0"]) == 0
+    skipped = json.loads(capsys.readouterr().out.strip())
+    assert skipped["value"] == 800.0 and len(skipped["dp_variants"]) == 7 and skipped["single_gpu_value"] is None
+    assert all(e["error"].startswith("skipped") for e in skipped["dp_variants"].values())
     # every variant child is told not to spawn anything itself, and keeps the caller's K / W
+    seen[:] = [x for x in seen if "--variants-budget" not in x[1]]
     for kind, argv in seen[1:]:
         assert "--variant-child" in argv and "--no-dp-variants" in argv and "--no-cpu-baseline" in argv
     assert all("50" in argv for kind, argv in seen[1:] if "--workload" not in argv)
