@@ -233,3 +233,41 @@ def test_observed_training_loops_run_on_the_device(gnn, oracle_mod):
     assert m2.steps == iters and m2.finished == 1 and np.array_equal(e.get_weights(), a.get_weights())
     with pytest.raises(gnn.GnnError):
         gnn._capi.check(gnn.load_library().gnn_mlp_train_sampled_observed(d._h, td.sampler._h, 3, B, 0.01, 0.9, 0, N + 1, val.ctypes.data_as(C.POINTER(C.c_double))))
+
+
+@pytest.mark.parametrize("kind", ["softmax_f32", "softmax_bf16", "general_f32"])
+def test_count_hits_large_blocks_and_both_classes(gnn, oracle_mod, kind):
+    """Evaluation over a data set in LARGE blocks takes the per-layer GEMM chain (from 2 048 rows per block on, plan.hip: do_forward)
+    instead of the small-net kernels: the same count as with 128-row blocks up to rows whose top-2 margin is within rounding, for both
+    NeuralNet classes and in bf16; against the oracle's rule on every safe row (f32)."""
+    dims, N = [784, 300, 100, 10], 5000
+    rng = np.random.default_rng(21)
+    lab = rng.integers(0, 10, N)
+    proto = rng.random((10, 784)) * (rng.random((10, 784)) < 0.2)
+    X = np.clip(proto[lab] + 0.2 * rng.standard_normal((N, 784)) * (proto[lab] > 0), 0, 1)
+    Y = np.eye(10)[lab]
+    bf16 = kind.endswith("bf16")
+    make = (lambda mb: gnn.GeneralNeuralNet(dims, inner_act="sigmoid", last_act="sigmoid", max_batch=mb)) if kind.startswith("general") else \
+           (lambda mb: gnn.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn.DTYPE_BF16 if bf16 else gnn.DTYPE_F32, max_batch=mb))
+    small, big = make(128), make(4096)
+    tr = gnn.NeuralNetTrainer(X, Y, small)
+    tr.train(80, 0.1 if kind.startswith("general") else 0.01, 64, 0.9, False)
+    w = small.get_weights()
+    big.set_weights(w)
+    big.upload_dataset(X, Y)
+    hs, hb = small.count_hits_range(0, N), big.count_hits_range(0, N)     # 40 blocks of 128 (8 left over) / 4096 + 904 rows
+    assert 0.15 * N < hs <= N
+    if not bf16:
+        ref = (oracle_mod.OracleNet(dims, out_kind=oracle_mod.OUT_ACT_LOSS, inner_act=1, last_act=1) if kind.startswith("general")
+               else oracle_mod.OracleNet(dims))
+        ref.set_weights(w)
+        out = ref.propagate(X[:1500]) if kind.startswith("general") else ref.logits(X[:1500])
+        s = np.sort(out, axis=1)
+        unsafe = int(((s[:, -1] - s[:, -2]) <= (1e-4 if kind.startswith("general") else 1e-3)).sum())
+        want = int((ref.argmax(X[:1500]) == lab[:1500]).sum())
+        assert abs(small.count_hits_range(0, 1500) - want) <= unsafe
+        assert abs(big.count_hits_range(0, 1500) - want) <= unsafe
+        assert abs(hs - hb) <= 3          # (another summation order in the large blocks: only near-ties may move)
+    else:
+        assert abs(hs - hb) <= 0.01 * N   # (bf16: operands rounded the same way, accumulation order differs)
+    assert big.count_hits_range(4096, 904) + big.count_hits_range(0, 4096) == hb
