@@ -180,6 +180,16 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (which == 31) {
+        printf("---- round 4: the bf16 gradient + update products (each three times)\n");
+        for (int rep = 0; rep < 3; rep++) {
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 0", 4096, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 1", 2048, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 2", 2048, 1024, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("cfg5 gradient + update 1", 1024, 1024, 256);
+        }
+        return 0;
+    }
     if (which == 30) {
         printf("---- round 4: bf16 tile shapes on the products of configs[3] that run few or memory-bound workgroups (each twice)\n");
         for (int rep = 0; rep < 2; rep++) {
