@@ -411,9 +411,10 @@ def other_configs():
         except Exception as e:   # a config that fails must not take the headline down with it
             out[name] = {"error": "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0])}
     # inference / evaluation throughput: testOnTrainingData (MT:181-197) over 60 000 resident rows as ONE call
-    # (gnn_mlp_count_hits_range), on a handle sized like a training handle (blocks of 128 rows) and on one sized for evaluation
-    for name, mb in [("inference configs[1], 60000 rows, blocks of 128 (a training handle)", 128),
-                     ("inference configs[1], 60000 rows, blocks of 16384", 16384)]:
+    # (gnn_mlp_count_hits_range: blocks of up to 16 384 rows through the handle's evaluation workspace), on a handle sized for
+    # training (max_batch 128: the one-call-per-block form beside it walks 469 blocks) and on one sized for evaluation
+    for name, mb in [("inference configs[1], 60000 rows, a training handle (max_batch 128)", 128),
+                     ("inference configs[1], 60000 rows, max_batch 16384", 16384)]:
         try:
             line = bc.run_inference("2", 60000, mb)
             out[name] = {"samples_per_s": line["value"], "ms_per_pass": line["ms_per_pass"], "rows": line["rows"], "max_batch": mb,

@@ -32,6 +32,8 @@ void read_env(gnn_mlp *h) {
     h->env_defer_off = is("GNN_MLP_DEFER", "0");
     const char *fg = getenv("GNN_MLP_FIRST_GEMM_ROWS"); // development: from how many rows on the first layer runs as a tiled GEMM (0 = never)
     if (fg) h->first_gemm_rows = atoi(fg);
+    const char *er = getenv("GNN_MLP_EVAL_ROWS");
+    if (er) h->eval_rows_cap = atoi(er);
 }
 } // namespace
 
@@ -237,7 +239,7 @@ int gnn_mlp_destroy(gnn_mlp_t *h) { return guarded([&]() -> int {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
-    fr(h->W); fr(h->V); fr(h->G_own); fr(h->act0_alt);
+    fr(h->W); fr(h->V); fr(h->G_own); fr(h->act0_alt); free_eval_workspace(h);
     for (float *p : h->act) fr(p);
     for (float *p : h->delta) fr(p);
     fr(h->logits); fr(h->prob); fr(h->ybuf); fr(h->lossv); fr(h->labels); fr(h->idxbuf);
@@ -556,8 +558,12 @@ int gnn_mlp_count_hits_range(gnn_mlp_t *h, int64_t first, int64_t n, int64_t *hi
     TRY(cnt.alloc(sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), h->stream));
     const int Lm = h->L - 1;
-    for (int64_t off = 0; off < n; off += h->max_batch) {
-        const int B = (int)std::min<int64_t>(h->max_batch, n - off);
+    const int block = eval_block_rows(h, n); // up to 16 384 rows through the evaluation workspace (f32), else max_batch
+    int rc_ws = GNN_OK;
+    EvalScope scope(h, block, &rc_ws);
+    if (rc_ws != GNN_OK) return rc_ws;
+    for (int64_t off = 0; off < n; off += block) {
+        const int B = (int)std::min<int64_t>(block, n - off);
         const float *y = h->DY + (size_t)(first + off) * h->ld[Lm];
         do_forward(h, h->DX + (size_t)(first + off) * h->ld[0], nullptr, B, false, false, true);
         hipLaunchKernelGGL(count_hits_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream,

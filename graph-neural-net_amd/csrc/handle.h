@@ -121,6 +121,19 @@ struct gnn_mlp {
     float *act0_alt = nullptr;
     bool env_defer_off = false;  // GNN_MLP_DEFER=0: the update in the call that computed it (four launches; development)
 
+    // Evaluation workspace (f32 nets): forward-only buffers for blocks of MORE rows than max_batch -- evaluation over a data set
+    // (gnn_mlp_count_hits_range) and the trainer's validation pass (validate(), NNT:102-113: 601 rows at MNIST's size) then run
+    // in blocks of up to kEvalRows rows whatever the handle's max_batch, which is sized for TRAINING batches.  Allocated on first
+    // use, grown on demand; EvalScope (plan.hip) swaps the buffers in for the duration of a forward pass.
+    static constexpr int kEvalRows = 16384;
+    int eval_rows_cap = kEvalRows; // GNN_MLP_EVAL_ROWS (development; 0 = blocks of max_batch as until round 4)
+    struct EvalWorkspace {
+        int rows = 0;
+        std::vector<float *> act;   // act[1..L-2]
+        float *logits = nullptr, *prob = nullptr, *lossv = nullptr;
+        int32_t *labels = nullptr;
+    } evalws;
+
     hipError_t launch_error = hipSuccess; // first refused launch of a module / function-pointer kernel since the last check
     const int32_t *cur_idx = nullptr; // device row indices of the batch being stepped (fused path reads rows through them)
 
@@ -311,6 +324,15 @@ void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_pr
 void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_update, float step_over_b, float momentum,
                  bool resident = false);
 void maybe_specialize(gnn_mlp *h);
+// rows a forward-only block may have on this handle: max_batch, or kEvalRows through the evaluation workspace (f32)
+int eval_block_rows(const gnn_mlp *h, int64_t rows_wanted);
+struct EvalScope { // for blocks above max_batch: the evaluation workspace's buffers stand in for act[1..], logits, prob, lossv, labels
+    gnn_mlp *h; bool on = false;
+    EvalScope(gnn_mlp *h_, int rows, int *rc);
+    ~EvalScope();
+    void swap();
+};
+void free_eval_workspace(gnn_mlp *h);
 bool can_defer_update(const gnn_mlp *h);
 int step_on_host_batch_deferred(gnn_mlp *h, int B, double step, double momentum); // act[0] / ybuf hold the staged batch
 void flush_pending_update(gnn_mlp *h);

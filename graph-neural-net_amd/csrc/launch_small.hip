@@ -193,6 +193,7 @@ void fused_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool back
     }
     {
         Mid4Params m4 = h->mid4p;
+        for (int l = 1; l < h->L - 1; l++) m4.act[l] = h->act[l]; // (the evaluation workspace may stand in: plan.hip, EvalScope)
         m4.slabs = h->slabs; m4.slab_rows = h->cap_rows; m4.n_slabs = h->n_slabs;
         m4.Y = y; m4.ldy = h->ld[h->L - 1];
         m4.prob = want_prob ? h->prob : nullptr;

@@ -309,6 +309,53 @@ int step_on_rows(gnn_mlp *h, const float *a0, const float *y, int B, double step
     return GNN_OK;
 }
 
+// ---- evaluation workspace (handle.h: EvalWorkspace) -----------------------------------------------------------------------
+int eval_block_rows(const gnn_mlp *h, int64_t rows_wanted) {
+    int cap = h->max_batch;
+    if (h->dtype == GNN_DTYPE_F32 && !h->cur_idx) cap = std::max(cap, h->eval_rows_cap);
+    return (int)std::min<int64_t>(cap, rows_wanted);
+}
+void free_eval_workspace(gnn_mlp *h) {
+    gnn_mlp::EvalWorkspace &w = h->evalws;
+    for (float *p : w.act) if (p) (void)hipFree(p);
+    w.act.clear();
+    if (w.logits) (void)hipFree(w.logits);
+    if (w.prob) (void)hipFree(w.prob);
+    if (w.lossv) (void)hipFree(w.lossv);
+    if (w.labels) (void)hipFree(w.labels);
+    w.logits = w.prob = w.lossv = nullptr; w.labels = nullptr; w.rows = 0;
+}
+static int ensure_eval_workspace(gnn_mlp *h, int rows) {
+    gnn_mlp::EvalWorkspace &w = h->evalws;
+    const int want = pad_up(rows);
+    if (w.rows >= want) return GNN_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream)); // (a smaller workspace may still be read by a queued pass)
+    free_eval_workspace(h);
+    w.act.assign((size_t)h->L, nullptr);
+    const size_t r = (size_t)want;
+    for (int l = 1; l < h->L - 1; l++) TRY(dev_alloc(&w.act[l], r * h->ld[l], h->stream));
+    TRY(dev_alloc(&w.logits, r * h->ld[h->L - 1], h->stream));
+    TRY(dev_alloc(&w.prob, r * h->ld[h->L - 1], h->stream));
+    TRY(dev_alloc(&w.lossv, r, h->stream));
+    TRY(dev_alloc(&w.labels, r, h->stream));
+    w.rows = want;
+    return GNN_OK;
+}
+EvalScope::EvalScope(gnn_mlp *h_, int rows, int *rc) : h(h_) {
+    *rc = GNN_OK;
+    if (rows <= h->max_batch) return; // the handle's own buffers hold the block
+    *rc = ensure_eval_workspace(h, rows);
+    if (*rc != GNN_OK) return;
+    swap();
+    on = true;
+}
+EvalScope::~EvalScope() { if (on) swap(); }
+void EvalScope::swap() {
+    gnn_mlp::EvalWorkspace &w = h->evalws;
+    for (int l = 1; l < h->L - 1; l++) std::swap(h->act[l], w.act[l]);
+    std::swap(h->logits, w.logits); std::swap(h->prob, w.prob); std::swap(h->lossv, w.lossv); std::swap(h->labels, w.labels);
+}
+
 // ---- host batches with the update deferred into the next call (handle.h: PendingUpdate) ----------------------------------
 // f32 nets on the two-launch path, outside stream capture (a captured sequence must be self-contained)
 bool can_defer_update(const gnn_mlp *h) {

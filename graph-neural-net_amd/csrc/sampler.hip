@@ -110,8 +110,12 @@ namespace host {
 // (dataset rows [0, n)), block by block on the handle's stream, summed into ONE fp64 slot on the device.
 int validation_loss_sum(gnn_mlp *h, int n, double *d_out) {
     const int Lm = h->L - 1;
-    for (int off = 0; off < n; off += h->max_batch) {
-        const int B = std::min(h->max_batch, n - off);
+    const int block = eval_block_rows(h, n); // (601 rows at MNIST's size: ONE block through the evaluation workspace instead of five of max_batch)
+    int rc_ws = GNN_OK;
+    EvalScope scope(h, block, &rc_ws);
+    if (rc_ws != GNN_OK) return rc_ws;
+    for (int off = 0; off < n; off += block) {
+        const int B = std::min(block, n - off);
         do_forward(h, h->DX + (size_t)off * h->ld[0], h->DY + (size_t)off * h->ld[Lm], B, false, true, false);
         hipLaunchKernelGGL(sum_loss_kernel, dim3(1), dim3(256), 0, h->stream, LossSumParams{h->lossv, B, d_out, off > 0 ? 1 : 0});
     }

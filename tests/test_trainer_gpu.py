@@ -271,3 +271,32 @@ def test_count_hits_large_blocks_and_both_classes(gnn, oracle_mod, kind):
     else:
         assert abs(hs - hb) <= 0.01 * N   # (bf16: operands rounded the same way, accumulation order differs)
     assert big.count_hits_range(4096, 904) + big.count_hits_range(0, 4096) == hb
+
+
+def test_evaluation_workspace_blocks_above_max_batch(gnn, monkeypatch):
+    """A handle sized for training batches (max_batch 32) evaluates and validates in blocks of up to 16 384 rows through its
+    evaluation workspace (csrc/plan.hip: EvalScope): against GNN_MLP_EVAL_ROWS=0 (blocks of max_batch, the form until round 4).
+    Below 2 048 rows per block the kernels are the same per row (exact equality); above, the GEMM chain (near-ties may move)."""
+    dims, N, B = [784, 100, 50, 10], 3000, 32
+    rng = np.random.default_rng(33)
+    lab = rng.integers(0, 10, N)
+    proto = rng.random((10, 784)) * (rng.random((10, 784)) < 0.2)
+    X = np.clip(proto[lab] + 0.25 * rng.standard_normal((N, 784)) * (proto[lab] > 0), 0, 1)
+    Y = np.eye(10)[lab]
+    ws = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    monkeypatch.setenv("GNN_MLP_EVAL_ROWS", "0")
+    plain = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    monkeypatch.delenv("GNN_MLP_EVAL_ROWS")
+    ta, tb = gnn.NeuralNetTrainer(X, Y, ws), gnn.NeuralNetTrainer(X, Y, plain)
+    import io
+    oa, ob = io.StringIO(), io.StringIO()
+    ta.train(40, 0.01, B, 0.9, False, observer=oa)       # validation: 31 rows = one block of 31 in the plain form too
+    tb.train(40, 0.01, B, 0.9, False, observer=ob)
+    assert np.array_equal(ws.get_weights(), plain.get_weights())
+    assert oa.getvalue() == ob.getvalue()
+    assert ws.count_hits_range(0, 1900) == plain.count_hits_range(0, 1900)         # one block of 1 900 / 60 blocks of 32: the same kernels per row
+    assert abs(ws.count_hits_range(0, N) - plain.count_hits_range(0, N)) <= 3     # one block of 3 000: the GEMM chain
+    assert ws.count_hits_range(100, 7) == plain.count_hits_range(100, 7)
+    # steps after an evaluation: the workspace was swapped out again
+    ta.train(5, 0.01, B, 0.9, False); tb.train(5, 0.01, B, 0.9, False)
+    assert np.array_equal(ws.get_weights(), plain.get_weights())

@@ -33,3 +33,26 @@ for dtype, name in ((gnn_amd.DTYPE_F32, "f32"), (gnn_amd.DTYPE_BF16, "bf16")):
     print("%s train_sampled: %.2f us/step (%.3g samples/s); train_range on the same data: %.2f us/step"
           % (name, dt / steps * 1e6, steps * B / dt, dr / steps * 1e6))
     net.close()
+
+# The loop MNISTTrainer actually runs (MT:150 passes a ProgressBar AND an observer, NNT:68-72): gradientStep + validate(1 % of the
+# data) per iteration, at MNIST's size (60 000 rows: 601 validation rows), on a handle sized for training batches of 128.
+import io
+n2 = 60000
+X2 = rng.random((n2, 784), dtype=np.float32) * (rng.random((n2, 784), dtype=np.float32) < 0.19)
+Y2 = np.eye(10, dtype=np.float32)[rng.integers(0, 10, n2)]
+net = gnn_amd.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+t = tr.NeuralNetTrainer(X2, Y2, net)
+obs = io.StringIO()
+t.train(200, 0.0125, B, 0.9, observer=obs)
+net.synchronize()
+it = 2000
+t0 = time.perf_counter()
+t.train(it, 0.0125, B, 0.9, observer=obs)
+net.synchronize()
+dt = time.perf_counter() - t0
+print("observed loop (step + validate(601 rows) per iteration, 60 000 rows resident): %.2f us/iteration (%.3g training samples/s)" % (dt / it * 1e6, it * B / dt))
+t0 = time.perf_counter()
+hits = net.count_hits_range(0, n2)
+dt = time.perf_counter() - t0
+print("testOnTrainingData over the 60 000 rows on the same handle (max_batch 128): %.2f ms, %.3g rows/s" % (dt * 1e3, n2 / dt))
+net.close()
