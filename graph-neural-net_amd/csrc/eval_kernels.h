@@ -45,4 +45,26 @@ static __global__ __launch_bounds__(256) void sum_loss_kernel(LossSumParams p) {
     if (threadIdx.x == 0) *p.out = (p.accumulate ? *p.out : 0.0) + part[0];
 }
 
+// One workgroup per ROW of a [n_rows][stride] matrix of per-sample losses: out[row] = the sum of its first `cols` entries, in fp64,
+// one fixed order.  The observed training loop keeps every iteration's validation losses in such a matrix and sums them ONCE at
+// the end of the call: a reduction launch per iteration (4.9 us each, profiles/r04/observed_loop_kernel_stats.csv) was 13 % of
+// the loop.
+struct RowSumParams {
+    const float *rows; int64_t stride; int cols;
+    double *out;
+};
+static __global__ __launch_bounds__(256) void sum_rows_kernel(RowSumParams p) {
+    __shared__ double part[256];
+    const float *r = p.rows + (size_t)blockIdx.x * p.stride;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < p.cols; i += 256) s += (double)r[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.out[blockIdx.x] = part[0];
+}
+
 } // namespace gnn

@@ -301,6 +301,9 @@ void launch_tile_step(gnn_mlp *h, int gsrc, int gdst, const NextBatch *next, con
 // ---- sampler.hip ---------------------------------------------------------------------------------
 // validate(validation_size) (NNT:102-113) on the device: the summed loss of dataset rows [0, n) into *d_out (fp64, device)
 int validation_loss_sum(gnn_mlp *h, int n, double *d_out);
+// the same pass with the per-sample losses LEFT in loss_row[0..n) (device; the caller sums rows later): one block, no reduction launch.
+// false when the pass needs more than one block (n above the evaluation block size): the caller then takes validation_loss_sum
+bool validation_losses_to_row(gnn_mlp *h, int n, float *loss_row, int *rc);
 
 // ---- launch_misc.hip: encodings, gathers, the flat update ---------------------------------------
 void launch_convert_rows(gnn_mlp *h, const double *src, int d, float *dst, int ld, int64_t rows, int64_t rows_pad, int act, int apply_act);

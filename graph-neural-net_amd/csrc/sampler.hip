@@ -121,13 +121,25 @@ int validation_loss_sum(gnn_mlp *h, int n, double *d_out) {
     }
     return GNN_OK;
 }
+bool validation_losses_to_row(gnn_mlp *h, int n, float *loss_row, int *rc) {
+    *rc = GNN_OK;
+    if (eval_block_rows(h, n) < n) return false;
+    const int Lm = h->L - 1;
+    EvalScope scope(h, n, rc);
+    if (*rc != GNN_OK) return true;
+    float *keep = h->lossv;
+    h->lossv = loss_row; // (the forward kernels write loss[row]: straight into the matrix's row)
+    do_forward(h, h->DX, h->DY, n, false, true, false);
+    h->lossv = keep;
+    return true;
+}
 } // namespace host
 } // namespace gnn
 
 // The loop NNT:60-92 on a resident dataset; d_val != null: the observed variants (NNT:68-72, 75-79) -- after iteration i the
 // summed validation loss of rows [0, validation_size) goes to d_val[i] (device).
 static int train_sampled_impl(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, int batch, double step, double momentum,
-                              int noise, int validation_size, double *d_val) {
+                              int noise, int validation_size, double *d_val, float *d_rows = nullptr, int64_t row_stride = 0) {
     TRY(check_handle(h));
     if (!s) return fail(GNN_ERR_BAD_ARG, "null sampler");
     TRY(check_step_args(h, batch, step, noise));
@@ -275,7 +287,13 @@ static int train_sampled_impl(gnn_mlp_t *h, gnn_sampler_t *s, int iterations, in
             rc = step_on_device_indices(h, d_idx + so + (size_t)(i - i0) * batch, ccnt[i - i0], step, momentum);
             // (the validation pass reads the weights the step has just written; it touches neither the slabs the step's tile
             //  kernel made for the next batch nor the staged rows, so the chain of two-launch steps runs on behind it)
-            if (rc == GNN_OK && d_val) rc = validation_loss_sum(h, validation_size, d_val + i);
+            if (rc == GNN_OK && d_val) {
+                // the per-sample losses of iteration i stay in row i of d_rows (summed once, behind the loop); a validation set of
+                // more than one block is summed block by block as before
+                int vrc = GNN_OK;
+                if (d_rows && validation_losses_to_row(h, validation_size, d_rows + (size_t)i * row_stride, &vrc)) rc = vrc;
+                else rc = validation_loss_sum(h, validation_size, d_val + i);
+            }
         }
     }
     // (on an early exit the sampler stops after the chunk it is drawing: its state stays well defined)
@@ -297,9 +315,19 @@ int gnn_mlp_train_sampled_observed(gnn_mlp_t *h, gnn_sampler_t *s, int iteration
     if (!val_loss) return fail(GNN_ERR_BAD_ARG, "null output");
     if (iterations <= 0) return fail(GNN_ERR_BAD_ARG, "iterations must be positive (NNT:62)");
     if (validation_size <= 0 || validation_size > h->dataset_n) return fail(GNN_ERR_BAD_ARG, "validation size outside the dataset (NNT:104)");
-    DevScratch dv;
+    DevScratch dv, drows;
     TRY(dv.alloc(sizeof(double) * (size_t)iterations));
-    TRY(train_sampled_impl(h, s, iterations, batch, step, momentum, noise, validation_size, dv.as<double>()));
+    // one row of per-sample losses per iteration when the validation set is ONE forward block (601 rows at MNIST's size): the rows
+    // are summed by one launch behind the loop instead of one per iteration.  (Capped at 1 GiB: longer calls sum per iteration.)
+    const int64_t stride = pad_up(validation_size);
+    const bool rows_form = eval_block_rows(h, validation_size) >= validation_size && (int64_t)iterations * stride * 4 <= (1ll << 30);
+    if (rows_form) TRY(drows.alloc(sizeof(float) * (size_t)iterations * (size_t)stride));
+    TRY(train_sampled_impl(h, s, iterations, batch, step, momentum, noise, validation_size, dv.as<double>(), rows_form ? drows.as<float>() : nullptr, stride));
+    if (rows_form) {
+        hipLaunchKernelGGL(sum_rows_kernel, dim3(iterations), dim3(256), 0, h->stream, RowSumParams{drows.as<float>(), stride, validation_size, dv.as<double>()});
+        TRY_LAUNCHES(h);
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     // (train_sampled_impl has waited for the stream: every sum is in place)
     HIP_TRY(hipMemcpy(val_loss, dv.p, sizeof(double) * (size_t)iterations, hipMemcpyDeviceToHost));
     for (int i = 0; i < iterations; i++) val_loss[i] /= (double)validation_size; // NNT:112
