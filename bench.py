@@ -82,6 +82,13 @@ def parse_args(argv=None):
                          "devices (gnn_mlp_dp_*: what a single-threaded JVM caller uses)")
     ap.add_argument("--dp-reducer", choices=["rccl", "direct", "direct_rs"], default="rccl",
                     help="--dp-impl library: RCCL all-reduce, or the peer-memory reducers (all-read-all / reduce-scatter + gather)")
+    ap.add_argument("--dp-exchange", choices=["auto", "torch", "library"], default="auto",
+                    help="--dp-impl ranks: the all-reduce through torch.distributed, or by the library itself inside its step loop "
+                         "(gnn_mlp_rccl_*: each rank attaches an RCCL communicator to its handle; K steps are ONE call).  auto = on "
+                         "more than one rank with RCCL the library's loop first and, should that attempt fail or overrun "
+                         "--attempt-timeout, FRESH ranks through torch.distributed; torch on one rank and with other backends")
+    ap.add_argument("--attempt-timeout", type=float, default=420.0,
+                    help="seconds an attempt of the headline may take when another attempt can follow it")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control flow on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -113,20 +120,46 @@ def free_port():
     return p
 
 
-def child_argv(argv, dp_mode):
-    """The caller's flags with the graph/eager decision made explicit."""
+def child_argv(argv, dp_mode, exchange=None):
+    """The caller's flags with the graph/eager decision (and, when given, the exchange) made explicit."""
     out, skip = [], False
     for a in argv:
         if skip:
             skip = False
             continue
-        if a == "--dp-mode":
+        if a == "--dp-mode" or (exchange is not None and a == "--dp-exchange"):
             skip = True
             continue
         if a.startswith("--dp-mode=") or a == "--no-graph" or a == "--inject-capture-failure":
             continue
+        if exchange is not None and a.startswith("--dp-exchange="):
+            continue
         out.append(a)
-    return out + ["--dp-mode", dp_mode]
+    return out + ["--dp-mode", dp_mode] + ([] if exchange is None else ["--dp-exchange", exchange])
+
+
+def attempt_plan(args, world):
+    """[(dp_mode, exchange)] in the order they are tried, each attempt in FRESH processes.
+    More than one rank over RCCL: first the library's own step loop (gnn_mlp_rccl_*: gradient kernels, ncclAllReduce, update
+    kernel enqueued by ONE call per K steps -- on a world of one 16.6 us per step where the per-step Python of the
+    torch.distributed form costs 41, profiles/r04/dp_path_world1.log), then eager steps through torch.distributed.  Graph replay
+    of the torch form on more than one rank stays opt-in (`--dp-mode graph`): the RCCL + hipGraph capture has only ever run on a
+    world of one, and a capture that HANGS would leave the run without a number; the test hook asks for the failing attempt
+    followed by the eager one.  One rank (`--dp-path`): the graph attempt, then eager."""
+    if args.dp_mode != "auto":
+        modes = [args.dp_mode]
+    elif world > 1:
+        modes = ["graph", "eager"] if args.inject_capture_failure else ["eager"]
+    else:
+        modes = ["graph", "eager"]
+    ex = args.dp_exchange
+    if ex == "auto":
+        if world > 1 and args.backend == "nccl" and not args.share_gpu and not args.inject_capture_failure and args.dp_mode in ("auto", "eager"):
+            return [("eager", "library")] + [(m, "torch") for m in modes]
+        ex = "torch"
+    if ex == "library":
+        return [("eager", "library")]
+    return [(m, ex) for m in modes]
 
 
 def clean_env():
@@ -167,11 +200,11 @@ def end_process_group(p):
         pass
 
 
-def run_group(argv, world, dp_mode, inject, timeout=None, stderr_to=None):
+def run_group(argv, world, dp_mode, inject, timeout=None, stderr_to=None, exchange=None):
     """Starts `world` fresh ranks of this script; returns (worst exit code, rank 0's stdout).  timeout: seconds after which
     every rank is ended and 124 returned; stderr_to: a file the ranks' stderr goes to instead of this process's."""
     port = free_port()
-    cmd = [sys.executable, os.path.abspath(__file__)] + child_argv(argv, dp_mode)
+    cmd = [sys.executable, os.path.abspath(__file__)] + child_argv(argv, dp_mode, exchange)
     if inject:
         cmd.append("--inject-capture-failure")
     procs = []
@@ -257,10 +290,12 @@ def dp_variant_specs(args):
         ("library rccl f32 (one process over N devices, ncclAllReduce inside the library)", "single", lib + ["--dp-reducer", "rccl"]),
         ("library direct f32 (peer-memory reduction fused into the tile kernel)", "single", lib + ["--dp-reducer", "direct"]),
         ("library direct_rs f32 (peer-memory reduce-scatter, gather while updating)", "single", lib + ["--dp-reducer", "direct_rs"]),
-        ("ranks bf16 (BASELINE configs[2]: bf16 operands, global batch 128 N, RCCL all-reduce)", "group", ranks + ["--dtype", "bf16"]),
+        ("ranks f32, RCCL inside the library's step loop (gnn_mlp_rccl_*: K steps are one call per rank)", "group", ranks + ["--dp-exchange", "library"]),
+        ("ranks f32, all-reduce through torch.distributed, eager steps", "group", ranks + ["--dp-exchange", "torch"]),
+        ("ranks bf16 (BASELINE configs[2]: bf16 operands, global batch 128 N, RCCL all-reduce)", "group", ranks + ["--dtype", "bf16", "--dp-exchange", "torch"]),
         ("library direct bf16 (configs[2]'s arithmetic, one process over N devices)", "single", lib + ["--dp-reducer", "direct", "--dtype", "bf16"]),
         ("ranks configs[4] f32 (784-1024-1024-1024-10, 256 rows per GPU, RCCL all-reduce of 11.6 MB)", "group",
-         ["--gpus", str(n), "--steps", str(k4), "--warmup", str(w4), "--backend", args.backend, "--workload", "configs4"] + tail),
+         ["--gpus", str(n), "--steps", str(k4), "--warmup", str(w4), "--backend", args.backend, "--workload", "configs4", "--dp-exchange", "torch"] + tail),
     ]
 
 
@@ -322,16 +357,12 @@ def merge_variants(headline_text, args):
 
 
 def launch(args, argv):
-    modes = [args.dp_mode]
-    if args.dp_mode == "auto":
-        # N > 1 defaults to EAGER steps: with a collective of >= ~20 us in every step the GPU, not the host, bounds the
-        # step either way, and the RCCL + hipGraph capture has only ever run on a world of one -- a capture that HANGS
-        # (rather than fails) on a real multi-GPU world would leave the run without a number.  `--dp-mode graph` asks
-        # for it; the test hook asks for the failing attempt followed by the eager one.
-        modes = ["graph", "eager"] if args.inject_capture_failure else ["eager"]
+    plan = attempt_plan(args, args.gpus)
     rc, out0 = 1, ""
-    for i, mode in enumerate(modes):
-        rc, out0 = run_group(argv, args.gpus, mode, args.inject_capture_failure and mode == "graph")
+    for i, (mode, exchange) in enumerate(plan):
+        last = i + 1 == len(plan)
+        rc, out0 = run_group(argv, args.gpus, mode, args.inject_capture_failure and mode == "graph",
+                             timeout=None if last else args.attempt_timeout, exchange=exchange)
         if rc == 0:
             lines = [l for l in out0.splitlines() if l.strip()]
             if len(lines) != 1:
@@ -342,10 +373,12 @@ def launch(args, argv):
                 text = merge_variants(text, args)
             print(text, flush=True)
             return 0
-        if i + 1 == len(modes):
+        if last:
             break
-        print("bench.py launcher: the hipGraph attempt failed in the ranks (%s); starting fresh ranks in eager mode"
-              % ("capture failed" if rc == EXIT_CAPTURE_FAILED else "exit code %d" % rc), file=sys.stderr)
+        what = "capture failed" if rc == EXIT_CAPTURE_FAILED else ("ended at the %.0f s limit" % args.attempt_timeout) if rc == 124 else "exit code %d" % rc
+        print("bench.py launcher: the %s attempt failed in the ranks (%s); starting fresh ranks: %s steps, exchange through %s"
+              % ("hipGraph" if mode == "graph" else "library-exchange" if exchange == "library" else mode, what, plan[i + 1][0],
+                 "the library" if plan[i + 1][1] == "library" else "torch.distributed"), file=sys.stderr)
     print("bench.py launcher: ranks failed (exit code %d)" % rc, file=sys.stderr)
     return rc
 
@@ -644,25 +677,30 @@ def supervise_own_rank(args, argv):
     Rank 0's supervisor then measures the other data-parallel forms (collect_variants) once the ranks are gone,
     and prints the merged line."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.dp_mode != "auto":
-        modes = [args.dp_mode]
-    elif world > 1:
-        modes = ["graph", "eager"] if args.inject_capture_failure else ["eager"]
-    else:
-        modes = ["graph", "eager"]
+    plan = attempt_plan(args, world)
     rc = 1
-    for i, mode in enumerate(modes):
+    for i, (mode, exchange) in enumerate(plan):
+        last = i + 1 == len(plan)
         env = dict(os.environ, GNN_BENCH_LAUNCHER="1")
         if i > 0:
-            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 1)
+            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + i)
             env.pop("TORCHELASTIC_USE_AGENT_STORE", None)   # rank 0 of the fresh group hosts the new store itself
-        cmd = [sys.executable, os.path.abspath(__file__)] + child_argv(argv, mode)
+        cmd = [sys.executable, os.path.abspath(__file__)] + child_argv(argv, mode, exchange)
         if args.inject_capture_failure and mode == "graph":
             cmd.append("--inject-capture-failure")
-        p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
-        rc = p.returncode
+        p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=sys.stderr, text=True, preexec_fn=child_setup(not last))
+        try:
+            out_text, _ = p.communicate(timeout=None if last else args.attempt_timeout)
+            rc = p.returncode
+        except subprocess.TimeoutExpired:   # (every rank's supervisor takes the same decision at the same limit)
+            end_process_group(p)
+            try:
+                out_text, _ = p.communicate(timeout=10)
+            except Exception:
+                out_text = ""
+            rc = 124
         if rc == 0:
-            text = p.stdout.strip()
+            text = (out_text or "").strip()
             if text and world > 1 and os.environ.get("RANK", "0") == "0" and not args.no_dp_variants and not args.variant_child:
                 time.sleep(2.0)   # (the other ranks' children left the barrier with this one's: let them release their devices)
                 try:
@@ -672,10 +710,24 @@ def supervise_own_rank(args, argv):
             if text:
                 print(text, flush=True)
             return 0
-        if i + 1 < len(modes):
-            print("bench.py rank supervisor: the hipGraph attempt failed (%s); fresh child in eager mode"
-                  % ("capture failed" if rc == EXIT_CAPTURE_FAILED else "exit code %d" % rc), file=sys.stderr)
+        if not last:
+            what = "capture failed" if rc == EXIT_CAPTURE_FAILED else ("ended at the %.0f s limit" % args.attempt_timeout) if rc == 124 else "exit code %d" % rc
+            print("bench.py rank supervisor: the %s attempt failed (%s); fresh child in %s mode, exchange through %s"
+                  % ("hipGraph" if mode == "graph" else "library-exchange" if exchange == "library" else mode, what, plan[i + 1][0],
+                     "the library" if plan[i + 1][1] == "library" else "torch.distributed"), file=sys.stderr)
     return rc if rc > 0 else 128 - rc
+
+
+class _ChecksumOnly:
+    """The part of data_parallel.HipEngine the lock-step check needs (the library-exchange ranks run their steps in C)."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def weights_checksum(self):
+        import numpy as np
+        w = self.net.get_weights()
+        return np.array([w.sum(), np.abs(w).sum()])
 
 
 def worker(args, argv):
@@ -753,6 +805,22 @@ def worker(args, argv):
 
         def run(first_batch, n, eager=False):
             net.train_range((first_batch % N_BATCHES) * BATCH, BATCH, n, STEP, MOMENTUM)
+    elif args.dp_exchange == "library":   # ("auto" is resolved by the launcher / the rank's supervisor; a bare rank takes torch)
+        # one process per GPU, the exchange inside the library's own step loop (include/gnn_mlp.h, gnn_mlp_rccl_*): rank 0's RCCL
+        # unique id travels through the process group's store, every rank attaches a communicator to its handle, and K steps are
+        # ONE call -- gradient kernels, ncclAllReduce on the same stream, update kernel, no Python between steps
+        from gnn_amd import data_parallel as dp
+        side = torch.cuda.Stream()
+        net.set_stream(side.cuda_stream)
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set("gnn_mlp_rccl_unique_id", net.rccl_unique_id())
+        net.rccl_attach(store.get("gnn_mlp_rccl_unique_id"), world, rank)
+        dp_mode = "eager"
+        stepper = dp.DataParallelStep(_ChecksumOnly(net), dist)   # (for the lock-step check and the world size only)
+
+        def run(first_batch, n, eager=False):
+            net.rccl_train_range((first_batch % N_BATCHES) * BATCH, BATCH, n, STEP, MOMENTUM)
     else:
         # data parallel (graph-neural-net_amd/data_parallel.py): kernels on a torch side stream that
         # is also the collective's stream, gradient buffer owned by torch so that RCCL reduces it in
@@ -883,7 +951,8 @@ def worker(args, argv):
                                    % (wl_label, "bf16 GEMM operands / f32 accumulate and masters" if bf16 else "fp32", BATCH,
                                       4 if not headline_shape else 2 if bf16 else 1),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
-                       "backend": None if dist is None else ("rccl" if args.backend == "nccl" else args.backend),
+                       "backend": None if dist is None else ("rccl inside the library's step loop (gnn_mlp_rccl_*)" if args.dp_exchange == "library"
+                                                             else "rccl" if args.backend == "nccl" else args.backend),
                        "world_size": None if dist is None else stepper.world,
                        "dp_mode": (None if dist is None else
                                    ("hipGraph replay of %d steps" % N_BATCHES if graphed is not None else "eager")),
@@ -908,13 +977,17 @@ def main():
     if world_env is not None and int(world_env) != args.gpus:
         args.gpus = int(world_env)
     is_dp = args.gpus > 1 or args.dp_path
-    first_mode = args.dp_mode if args.dp_mode != "auto" else (
-        "graph" if (args.backend == "nccl" and args.gpus == 1) or args.inject_capture_failure else "eager")
     supervised = os.environ.get("GNN_BENCH_LAUNCHER") == "1"
-    # a graph attempt is never made in an unsupervised process; and a rank of a world > 1 that someone else started
-    # (torch.distributed.run) is supervised too, so that rank 0's supervisor can add the dp variants afterwards
-    if is_dp and not supervised and (first_mode == "graph" or (world_env is not None and args.gpus > 1 and not args.no_dp_variants)):
-        sys.exit(supervise_own_rank(args, argv))
+    # a graph attempt -- and any attempt that another one may have to follow -- is never made in an unsupervised process; and a rank
+    # of a world > 1 that someone else started (torch.distributed.run) is supervised too, so that rank 0's supervisor can add the
+    # dp variants afterwards
+    if is_dp and not supervised:
+        plan = attempt_plan(args, args.gpus)
+        if plan[0][0] == "graph" or len(plan) > 1 or (world_env is not None and args.gpus > 1 and not args.no_dp_variants):
+            sys.exit(supervise_own_rank(args, argv))
+        args.dp_mode, args.dp_exchange = plan[0]
+    if args.dp_exchange == "auto":
+        args.dp_exchange = "torch"
     worker(args, argv)
 
 

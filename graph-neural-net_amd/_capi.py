@@ -63,6 +63,10 @@ SYMBOLS = [
     ("gnn_mlp_apply_update", C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
     ("gnn_mlp_hint_next_range", C.c_int, [_H, C.c_int64, C.c_int]),
     ("gnn_mlp_synchronize", C.c_int, [_H]),
+    ("gnn_mlp_rccl_unique_id", C.c_int, [C.c_void_p]),
+    ("gnn_mlp_rccl_attach", C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    ("gnn_mlp_rccl_detach", C.c_int, [_H]),
+    ("gnn_mlp_rccl_train_range", C.c_int, [_H, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double]),
     ("gnn_mlp_dp_create", C.c_int, [_ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
     ("gnn_mlp_dp_destroy", C.c_int, [_H]),
     ("gnn_mlp_dp_num_replicas", C.c_int, [_H]),

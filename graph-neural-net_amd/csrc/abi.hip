@@ -238,6 +238,7 @@ int gnn_mlp_destroy(gnn_mlp_t *h) { return guarded([&]() -> int {
     if (!h) return GNN_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    rccl_detach_handle(h);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->W); fr(h->V); fr(h->G_own); fr(h->act0_alt); free_eval_workspace(h);
     for (float *p : h->act) fr(p);

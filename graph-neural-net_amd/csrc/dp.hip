@@ -17,7 +17,10 @@ namespace {
 struct RcclApi {
     void *lib = nullptr;
     bool ok = false; // every entry point below resolved (a library that lacks one is closed again and never used)
+    struct UniqueId { char bytes[128]; }; // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
     int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*ReduceScatter)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -39,6 +42,8 @@ struct RcclApi {
             return false;
         }
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
         ReduceScatter = reinterpret_cast<decltype(ReduceScatter)>(dlsym(lib, "ncclReduceScatter"));
@@ -46,11 +51,11 @@ struct RcclApi {
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!CommInitAll || !CommDestroy || !AllReduce || !ReduceScatter || !AllGather || !GroupStart || !GroupEnd) {
+        if (!CommInitAll || !GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !ReduceScatter || !AllGather || !GroupStart || !GroupEnd) {
             *why = "RCCL lacks the expected entry points";
             (void)dlclose(lib);
             lib = nullptr;
-            CommInitAll = nullptr; CommDestroy = nullptr; AllReduce = nullptr; ReduceScatter = nullptr; AllGather = nullptr;
+            CommInitAll = nullptr; GetUniqueId = nullptr; CommInitRank = nullptr; CommDestroy = nullptr; AllReduce = nullptr; ReduceScatter = nullptr; AllGather = nullptr;
             GroupStart = nullptr; GroupEnd = nullptr; GetErrorString = nullptr;
             return false;
         }
@@ -194,6 +199,20 @@ int dp_direct_begin(gnn_mlp_dp *d, int r) {
     return GNN_OK;
 }
 
+} // namespace
+
+namespace gnn {
+namespace host {
+void rccl_detach_handle(gnn_mlp *h) {
+    if (!h->rccl_comm) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->rccl_comm);
+    h->rccl_comm = nullptr; h->rccl_ranks = 0; h->rccl_rank = 0;
+}
+} // namespace host
+} // namespace gnn
+
+namespace {
 int dp_check(const gnn_mlp_dp *d) { return d ? GNN_OK : fail(GNN_ERR_BAD_ARG, "null handle"); }
 int dp_check_steppable(const gnn_mlp_dp *d) {
     TRY(dp_check(d));
@@ -211,6 +230,76 @@ template <class F> int dp_guard_step(gnn_mlp_dp *d, F &&body) {
 } // namespace
 
 extern "C" {
+
+// ---- one process per GPU, the exchange inside the library's step loop ------------------------------------------------------
+int gnn_mlp_rccl_unique_id(void *id128) { return guarded([&]() -> int {
+    if (!id128) return fail(GNN_ERR_BAD_ARG, "null output");
+    std::string why;
+    if (!g_rccl.load(&why)) return fail(GNN_ERR_UNSUPPORTED, why);
+    RcclApi::UniqueId id{};
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc) return dp_rccl_fail(rc, "ncclGetUniqueId");
+    std::memcpy(id128, id.bytes, sizeof(id.bytes));
+    return GNN_OK;
+}); }
+
+int gnn_mlp_rccl_attach(gnn_mlp_t *h, const void *id128, int n_ranks, int rank) { return guarded([&]() -> int {
+    TRY(check_handle(h));
+    if (!id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(GNN_ERR_BAD_ARG, "bad communicator arguments");
+    if (h->rccl_comm) return fail(GNN_ERR_STATE, "the handle already has a communicator (gnn_mlp_rccl_detach first)");
+    std::string why;
+    if (!g_rccl.load(&why)) return fail(GNN_ERR_UNSUPPORTED, why);
+    RcclApi::UniqueId id{};
+    std::memcpy(id.bytes, id128, sizeof(id.bytes));
+    void *comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, n_ranks, id, rank); // (collective: returns when every rank has joined)
+    if (rc) return dp_rccl_fail(rc, "ncclCommInitRank");
+    h->rccl_comm = comm; h->rccl_ranks = n_ranks; h->rccl_rank = rank;
+    return GNN_OK;
+}); }
+
+int gnn_mlp_rccl_detach(gnn_mlp_t *h) { return guarded([&]() -> int {
+    TRY(check_handle(h));
+    rccl_detach_handle(h);
+    return GNN_OK;
+}); }
+
+int gnn_mlp_rccl_train_range(gnn_mlp_t *h, int64_t first, int B_local, int n_steps, double step, double momentum) { return guarded([&]() -> int {
+    TRY(check_handle(h));
+    if (!h->rccl_comm) return fail(GNN_ERR_STATE, "no communicator attached (gnn_mlp_rccl_attach)");
+    TRY(check_step_args(h, B_local, step, 0));
+    if (!h->DX) return fail(GNN_ERR_STATE, "no dataset uploaded");
+    if (n_steps <= 0) return fail(GNN_ERR_BAD_ARG, "n_steps must be positive (NNT:62)");
+    const int64_t nb = h->dataset_n / B_local;
+    if (nb <= 0 || first < 0 || first % B_local != 0) return fail(GNN_ERR_BAD_ARG, "first must be a multiple of B_local inside the dataset");
+    if (n_steps >= 64) try_specialize(h);
+    const int Lm = h->L - 1;
+    const int B_global = B_local * h->rccl_ranks;                 // batchSize of SCE:333: every rank holds B_local rows of the batch
+    const float sob = (float)(step / (double)B_global), mom = (float)momentum;
+    for (int s = 0; s < n_steps; s++) {
+        const int64_t row0 = ((first / B_local + s) % nb) * B_local;
+        // (1) this rank's partial gradient (the per-sample loop SCE:305-322 restricted to its rows) into the flat buffer
+        hint_range(h, ((first / B_local + s + 1) % nb) * B_local, B_local);
+        maybe_specialize(h);
+        do_gradient(h, h->DX + (size_t)row0 * h->ld[0], h->DY + (size_t)row0 * h->ld[Lm], B_local, false, 0.f, 0.f, true);
+        // (2) ONE sum of the flat buffer over the ranks, on the stream the kernels run on
+        const int rc = g_rccl.AllReduce(h->G, h->G, (size_t)h->n_pad, kNcclFloat, kNcclSum, h->rccl_comm, h->stream);
+        if (rc) return dp_rccl_fail(rc, "ncclAllReduce");
+        // (3) the identical update on every rank (SCE:327-342 with batchSize = B_global), by weight tiles, each tile going on to
+        //     the next batch's first-layer slab where the net takes the two-launch path
+        NextBatch nb_next{};
+        if (h->chain && take_next(h, &nb_next)) {
+            launch_tile_step(h, 2, 2, &nb_next, nullptr, PAD, sob, mom);
+            slabs_now_hold(h, nb_next, nb_next.idx != nullptr);
+        } else {
+            launch_flat_update(h, B_global, step, momentum);
+            h->slab_valid = false; h->have_next = false;
+        }
+        h->time++;
+        TRY_LAUNCHES(h);
+    }
+    return GNN_OK;
+}); }
 
 int gnn_mlp_dp_create(const int32_t *dims, int n_dims, int out_kind, int inner_act, int last_act, int loss, int64_t seed,
                       int dtype, const int32_t *devices, int n_dev, int max_batch, int reducer, gnn_mlp_dp_t **out) { return guarded([&]() -> int {

@@ -134,6 +134,9 @@ struct gnn_mlp {
         int32_t *labels = nullptr;
     } evalws;
 
+    // one process per GPU with the exchange inside the library's step loop (gnn_mlp_rccl_*, dp.hip): this rank's communicator
+    void *rccl_comm = nullptr; int rccl_ranks = 0, rccl_rank = 0;
+
     hipError_t launch_error = hipSuccess; // first refused launch of a module / function-pointer kernel since the last check
     const int32_t *cur_idx = nullptr; // device row indices of the batch being stepped (fused path reads rows through them)
 
@@ -336,6 +339,7 @@ struct EvalScope { // for blocks above max_batch: the evaluation workspace's buf
     void swap();
 };
 void free_eval_workspace(gnn_mlp *h);
+void rccl_detach_handle(gnn_mlp *h); // (dp.hip; gnn_mlp_destroy calls it)
 bool can_defer_update(const gnn_mlp *h);
 int step_on_host_batch_deferred(gnn_mlp *h, int B, double step, double momentum); // act[0] / ybuf hold the staged batch
 void flush_pending_update(gnn_mlp *h);

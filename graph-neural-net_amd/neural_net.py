@@ -260,6 +260,27 @@ class NeuralNet:
     def apply_update(self, B_global, step, momentum):
         _capi.check(self._lib.gnn_mlp_apply_update(self._h, int(B_global), float(step), float(momentum)))
 
+    # -- one process per GPU, the exchange inside the library's step loop (gnn_mlp_rccl_*) --------
+    @staticmethod
+    def rccl_unique_id():
+        """128 bytes from ncclGetUniqueId: rank 0 makes them, the caller hands them to every rank."""
+        buf = C.create_string_buffer(128)
+        _capi.check(_capi.load().gnn_mlp_rccl_unique_id(buf))
+        return buf.raw
+
+    def rccl_attach(self, unique_id, n_ranks, rank):
+        if len(unique_id) != 128:
+            raise ValueError("an RCCL unique id is 128 bytes")
+        _capi.check(self._lib.gnn_mlp_rccl_attach(self._h, C.c_char_p(bytes(unique_id)), int(n_ranks), int(rank)))
+
+    def rccl_detach(self):
+        _capi.check(self._lib.gnn_mlp_rccl_detach(self._h))
+
+    def rccl_train_range(self, first, B_local, n_steps, step, momentum):
+        """n_steps global gradientSteps: this rank's rows [first + s B_local, ...) per step, one ncclAllReduce of the flat gradient
+        per step inside the call, the identical update with batchSize = B_local * n_ranks."""
+        _capi.check(self._lib.gnn_mlp_rccl_train_range(self._h, int(first), int(B_local), int(n_steps), float(step), float(momentum)))
+
     def hint_next_range(self, first, B):
         """The next gradient computation will run on dataset rows [first, first+B) (speed only)."""
         _capi.check(self._lib.gnn_mlp_hint_next_range(self._h, int(first), int(B)))

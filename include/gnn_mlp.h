@@ -236,6 +236,23 @@ int gnn_mlp_forget_lookahead(gnn_mlp_t *h);
  * with gnn_mlp_set_stream. No reference counterpart. */
 int gnn_mlp_recover_stream(gnn_mlp_t *h);
 
+/* ---- one process per GPU, the exchange INSIDE the library's step loop -------------------------------------------------
+ * The partitioning of the hooks above (rows sharded over the ranks, ONE sum of the flat gradient per step, the identical
+ * update with batchSize = B_global, SCE:305-322 / SCE:333) with the sum done by the library itself: every rank process attaches
+ * an RCCL communicator to its handle (ncclCommInitRank; RCCL is loaded at run time) and then runs n_steps steps in ONE call --
+ * gradient kernels, ncclAllReduce on the same stream, update kernel, no host work of the caller's in between.
+ *   rank 0:      gnn_mlp_rccl_unique_id(id)            -> 128 bytes, handed to every rank by the caller (a torch.distributed
+ *                                                         store, MPI, a file: the library does no rendezvous of its own)
+ *   every rank:  gnn_mlp_rccl_attach(h, id, n_ranks, rank)   (collective: returns when all ranks have joined)
+ *                gnn_mlp_rccl_train_range(h, first, B_local, n_steps, step, momentum)   rows [first + s B_local, ..) of THIS
+ *                                                         rank's resident data set per step; batchSize = B_local * n_ranks
+ * Replicas stay bitwise identical (the all-reduce leaves the same bits on every rank).  UNVERIFIED beyond a world of one rank:
+ * the build boxes have one GPU. */
+int gnn_mlp_rccl_unique_id(void *id128);
+int gnn_mlp_rccl_attach(gnn_mlp_t *h, const void *id128, int n_ranks, int rank);
+int gnn_mlp_rccl_detach(gnn_mlp_t *h);
+int gnn_mlp_rccl_train_range(gnn_mlp_t *h, int64_t first, int B_local, int n_steps, double step, double momentum);
+
 /* ---- data parallel INSIDE the library: one handle, N device replicas -------------------------------
  * For a caller that is one thread in one process (the reference: NeuralNetTrainer calls gradientStep from
  * the JVM's main thread, NNT:83).  The batch's rows are dealt to the replicas in contiguous blocks, every

@@ -90,10 +90,11 @@ def check_dp_variants(line, n):
     The in-library RCCL form needs one DISTINCT device per replica, so on this box it is the variant that fails -- and shows that a
     failing variant leaves the line intact."""
     v = line["dp_variants"]
-    assert len(v) == 7
+    assert len(v) == 9
     by = lambda frag: next(v[k] for k in v if frag in k)
     assert "error" in by("library rccl") and any("distinct device" in l for l in by("library rccl")["stderr_tail"])
-    for frag, n_gpus, dtype in (("one GPU alone", 1, "f32"), ("library direct f32", n, "f32"), ("library direct_rs f32", n, "f32"),
+    assert "error" in by("RCCL inside the library's step loop")   # (two ranks of one RCCL communicator cannot share a device either)
+    for frag, n_gpus, dtype in (("one GPU alone", 1, "f32"), ("all-reduce through torch.distributed", n, "f32"), ("library direct f32", n, "f32"), ("library direct_rs f32", n, "f32"),
                                 ("ranks bf16", n, "bf16"), ("library direct bf16", n, "bf16"), ("ranks configs[4]", n, "f32")):
         e = by(frag)
         assert "error" not in e, (frag, e)
@@ -128,7 +129,7 @@ def test_bench_capture_failure_hands_over_to_fresh_eager_ranks():
     must stop using the GPU and exit, and the eager run must come from FRESH processes."""
     line, err = run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--inject-capture-failure", "--no-dp-variants", want_stderr=True)
     check(line, n_gpus=2, shared_gpu=True)
-    assert "hipGraph capture failed" in err and "starting fresh ranks in eager mode" in err
+    assert "hipGraph capture failed" in err and "starting fresh ranks: eager steps" in err
     assert line["config"]["dp_mode"] == "eager" and line["config"]["dp_replicas_identical"] is True
 
 
@@ -138,6 +139,16 @@ def test_bench_line_data_parallel_path():
     assert line["config"]["dp_replicas_identical"] is True
     assert line["config"]["dp_mode"] == "hipGraph replay of 64 steps"   # RCCL (world 1) is capturable
     assert line["config"]["backend"] == "rccl" and line["config"]["world_size"] == 1
+
+
+def test_bench_line_ranks_with_the_exchange_inside_the_library():
+    """--dp-exchange library on a world of one rank: the rank attaches an RCCL communicator to its handle (unique id through the
+    process group's store) and the K steps are ONE gnn_mlp_rccl_train_range call -- gradient kernels, ncclAllReduce, update kernel."""
+    line = run_bench("--dp-path", "--dp-exchange", "library")
+    check(line)
+    c = line["config"]
+    assert c["dp_replicas_identical"] is True and c["dp_mode"] == "eager" and c["world_size"] == 1
+    assert "inside the library" in c["backend"]
 
 
 def test_bench_capture_failure_under_external_launcher():

@@ -24,10 +24,11 @@ def test_child_argv_makes_the_mode_explicit():
 
 def test_launcher_relays_one_line_and_falls_back_to_fresh_eager_ranks(monkeypatch, capsys):
     b = _bench()
-    calls = []
+    calls, exchanges = [], []
 
-    def fake_group(argv, world, mode, inject):
+    def fake_group(argv, world, mode, inject, timeout=None, stderr_to=None, exchange=None):
         calls.append((world, mode))
+        exchanges.append((exchange, timeout))
         if mode == "graph":
             return b.EXIT_CAPTURE_FAILED, ""
         return 0, '{"n_gpus": %d}\n' % world
@@ -36,6 +37,7 @@ def test_launcher_relays_one_line_and_falls_back_to_fresh_eager_ranks(monkeypatc
     args = b.parse_args(["--gpus", "4", "--no-dp-variants"])
     assert b.launch(args, ["--gpus", "4", "--no-dp-variants"]) == 0
     assert calls == [(4, "eager")]
+    assert exchanges == [("library", args.attempt_timeout)]   # more than one rank over RCCL: the library's own step loop first, with a time limit
     assert capsys.readouterr().out.strip() == '{"n_gpus": 4}'
     # the test hook: a graph attempt that fails, then fresh ranks in eager mode
     calls.clear()
@@ -47,13 +49,13 @@ def test_launcher_relays_one_line_and_falls_back_to_fresh_eager_ranks(monkeypatc
     calls.clear()
     args = b.parse_args(["--gpus", "2", "--dp-mode", "graph"])
     assert b.launch(args, []) == b.EXIT_CAPTURE_FAILED and calls == [(2, "graph")]
-    monkeypatch.setattr(b, "run_group", lambda *a: (3, ""))
+    monkeypatch.setattr(b, "run_group", lambda *a, **k: (3, ""))
     assert b.launch(b.parse_args(["--gpus", "2", "--backend", "gloo"]), []) == 3
 
 
 def test_launcher_process_never_imports_torch():
     code = ("import sys; sys.path.insert(0, %r); import bench\n"
-            "bench.run_group = lambda *a: (0, '{\"ok\": 1}\\n')\n"
+            "bench.run_group = lambda *a, **k: (0, '{\"ok\": 1}\\n')\n"
             "sys.argv = ['bench.py', '--gpus', '8', '--no-dp-variants']\n"
             "try:\n    bench.main()\nexcept SystemExit as e:\n    assert e.code == 0, e.code\n"
             "assert 'torch' not in sys.modules and 'gnn_amd' not in sys.modules\n") % ROOT
@@ -92,7 +94,7 @@ def test_dp_variants_are_merged_and_a_failing_one_does_not_take_the_headline_dow
     b = _bench()
     seen = []
 
-    def fake_group(argv, world, mode, inject, timeout=None, stderr_to=None):
+    def fake_group(argv, world, mode, inject, timeout=None, stderr_to=None, exchange=None):
         seen.append(("group", tuple(argv)))
         if "--variant-child" not in argv:
             return 0, json.dumps({"value": 800.0, "n_gpus": world, "config": {"backend": "rccl"}}) + "\n"
@@ -117,7 +119,7 @@ def test_dp_variants_are_merged_and_a_failing_one_does_not_take_the_headline_dow
     line = json.loads(capsys.readouterr().out.strip())
     assert line["value"] == 800.0 and line["n_gpus"] == 8           # the headline is the one-process-per-GPU RCCL form
     v = line["dp_variants"]
-    assert len(v) == 7 and line["single_gpu_value"] == 110.0
+    assert len(v) == 9 and line["single_gpu_value"] == 110.0
     names = list(v)
     assert any("library rccl" in n for n in names) and any("direct_rs" in n for n in names) and any("configs[2]" in n for n in names)
     rccl = next(v[n] for n in names if "library rccl" in n)
@@ -130,7 +132,7 @@ def test_dp_variants_are_merged_and_a_failing_one_does_not_take_the_headline_dow
     args = b.parse_args(["--gpus", "8", "--steps", "50", "--warmup", "10", "--variants-budget", "0"])
     assert b.launch(args, ["--gpus", "8", "--steps", "50", "--warmup", "10", "--variants-budget", "0"]) == 0
     skipped = json.loads(capsys.readouterr().out.strip())
-    assert skipped["value"] == 800.0 and len(skipped["dp_variants"]) == 7 and skipped["single_gpu_value"] is None
+    assert skipped["value"] == 800.0 and len(skipped["dp_variants"]) == 9 and skipped["single_gpu_value"] is None
     assert all(e["error"].startswith("skipped") for e in skipped["dp_variants"].values())
     # every variant child is told not to spawn anything itself, and keeps the caller's K / W
     seen[:] = [x for x in seen if "--variants-budget" not in x[1]]
@@ -147,3 +149,32 @@ def test_children_do_not_inherit_an_outer_launchers_rendezvous(monkeypatch):
     e = b.clean_env()
     assert not any(k.startswith("TORCHELASTIC_") for k in e) and "WORLD_SIZE" not in e and "RANK" not in e and "MASTER_PORT" not in e
     assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_library_exchange_attempt_falls_back_to_fresh_ranks_through_torch(monkeypatch, capsys):
+    """More than one rank over RCCL: the first attempt runs the ranks with the exchange inside the library's step loop (K steps = one
+    call per rank); if it fails -- or overruns --attempt-timeout -- FRESH ranks run the torch.distributed form, and the line says which."""
+    import json
+    b = _bench()
+    seen = []
+
+    def fake_group(argv, world, mode, inject, timeout=None, stderr_to=None, exchange=None):
+        seen.append((mode, exchange, timeout))
+        if exchange == "library":
+            return 124, ""                                   # hangs in the communicator's set-up: ended at the limit
+        return 0, json.dumps({"n_gpus": world, "config": {"backend": "rccl"}}) + "\n"
+    monkeypatch.setattr(b, "run_group", fake_group)
+    args = b.parse_args(["--gpus", "8", "--no-dp-variants", "--attempt-timeout", "7"])
+    assert b.launch(args, ["--gpus", "8", "--no-dp-variants", "--attempt-timeout", "7"]) == 0
+    assert seen == [("eager", "library", 7.0), ("eager", "torch", None)]
+    out = capsys.readouterr()
+    assert json.loads(out.out.strip())["config"]["backend"] == "rccl" and "library-exchange attempt failed" in out.err
+    # the plans: one rank keeps the graph attempt; other backends, shared devices and explicit choices are not second-guessed
+    assert b.attempt_plan(b.parse_args(["--gpus", "1", "--dp-path"]), 1) == [("graph", "torch"), ("eager", "torch")]
+    assert b.attempt_plan(b.parse_args(["--gpus", "2", "--backend", "gloo"]), 2) == [("eager", "torch")]
+    assert b.attempt_plan(b.parse_args(["--gpus", "2", "--share-gpu"]), 2) == [("eager", "torch")]
+    assert b.attempt_plan(b.parse_args(["--gpus", "8", "--dp-exchange", "torch"]), 8) == [("eager", "torch")]
+    assert b.attempt_plan(b.parse_args(["--gpus", "8", "--dp-exchange", "library"]), 8) == [("eager", "library")]
+    assert b.attempt_plan(b.parse_args(["--gpus", "8", "--dp-mode", "graph"]), 8) == [("graph", "torch")]
+    got = b.child_argv(["--gpus", "8", "--dp-exchange", "auto", "--steps", "5"], "eager", "library")
+    assert got == ["--gpus", "8", "--steps", "5", "--dp-mode", "eager", "--dp-exchange", "library"]

@@ -150,3 +150,34 @@ def test_config3_world8_one_process_per_gpu_form_on_one_gpu(gnn):
         w, v = np_oracle.gradient_step_bf16(w, v, DIMS, X32[s * Bg:(s + 1) * Bg], Y[s * Bg:(s + 1) * Bg], 0.0125, 0.9, 0)
     assert np.abs(out[0][0] - w).max() <= 3e-4
     assert np.abs(out[0][1] - v).max() <= 3e-4
+
+
+def test_rccl_exchange_inside_the_library_world_of_one(gnn):
+    """gnn_mlp_rccl_*: a rank attaches an RCCL communicator (ncclGetUniqueId -> ncclCommInitRank, a world of ONE here) and runs n
+    steps in one call: gradient kernels -> ncclAllReduce of the flat gradient on the same stream -> update kernel.  With one rank
+    the sum is the identity, so the weights equal, bit for bit, the same steps through the hooks (compute_gradient_range +
+    apply_update with the next batch announced): the same kernels in the same order."""
+    dims, B, nb, steps = [784, 300, 100, 10], 128, 4, 9
+    rng = np.random.default_rng(44)
+    X = rng.random((B * nb, dims[0])) * (rng.random((B * nb, dims[0])) < 0.3)
+    Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B * nb)]
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    a.upload_dataset(X, Y); b.upload_dataset(X, Y)
+    with pytest.raises(gnn.GnnError):
+        a.rccl_train_range(0, B, 1, 0.0125, 0.9)          # no communicator yet
+    uid = gnn.NeuralNet.rccl_unique_id()
+    assert len(uid) == 128
+    a.rccl_attach(uid, 1, 0)
+    with pytest.raises(gnn.GnnError):
+        a.rccl_attach(uid, 1, 0)                          # already attached
+    a.rccl_train_range(B, B, steps, 0.0125, 0.9)
+    for s in range(steps):
+        b.hint_next_range(((1 + s + 1) % nb) * B, B)
+        b.compute_gradient_range(((1 + s) % nb) * B, B)
+        b.apply_update(B, 0.0125, 0.9)
+    assert a.time == steps == b.time
+    assert np.array_equal(a.get_weights(), b.get_weights()) and np.array_equal(a.get_momentum(), b.get_momentum())
+    a.rccl_detach()
+    a.train_range(0, B, 2, 0.0125, 0.9); b.train_range(0, B, 2, 0.0125, 0.9)   # the handle steps on without a communicator
+    assert np.array_equal(a.get_weights(), b.get_weights())
