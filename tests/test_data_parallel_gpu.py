@@ -152,17 +152,20 @@ def test_config3_world8_one_process_per_gpu_form_on_one_gpu(gnn):
     assert np.abs(out[0][1] - v).max() <= 3e-4
 
 
-def test_rccl_exchange_inside_the_library_world_of_one(gnn):
+@pytest.mark.parametrize("dtype,dims", [("f32", [784, 300, 100, 10]), ("bf16", [784, 300, 100, 10]), ("f32", [200, 512, 272, 10])],
+                         ids=["f32-two-launch", "bf16-two-launch", "f32-per-layer-gemms"])
+def test_rccl_exchange_inside_the_library_world_of_one(gnn, dtype, dims):
     """gnn_mlp_rccl_*: a rank attaches an RCCL communicator (ncclGetUniqueId -> ncclCommInitRank, a world of ONE here) and runs n
     steps in one call: gradient kernels -> ncclAllReduce of the flat gradient on the same stream -> update kernel.  With one rank
     the sum is the identity, so the weights equal, bit for bit, the same steps through the hooks (compute_gradient_range +
     apply_update with the next batch announced): the same kernels in the same order."""
-    dims, B, nb, steps = [784, 300, 100, 10], 128, 4, 9
+    B, nb, steps = 128, 4, 9
     rng = np.random.default_rng(44)
     X = rng.random((B * nb, dims[0])) * (rng.random((B * nb, dims[0])) < 0.3)
     Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B * nb)]
-    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
-    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B)
+    dt = gnn.DTYPE_BF16 if dtype == "bf16" else gnn.DTYPE_F32
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B, dtype=dt)
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, max_batch=B, dtype=dt)
     a.upload_dataset(X, Y); b.upload_dataset(X, Y)
     with pytest.raises(gnn.GnnError):
         a.rccl_train_range(0, B, 1, 0.0125, 0.9)          # no communicator yet
