@@ -32,6 +32,8 @@ void read_env(gnn_mlp *h) {
     h->env_defer_off = is("GNN_MLP_DEFER", "0");
     const char *fg = getenv("GNN_MLP_FIRST_GEMM_ROWS"); // development: from how many rows on the first layer runs as a tiled GEMM (0 = never)
     if (fg) h->first_gemm_rows = atoi(fg);
+    const char *fw = getenv("GNN_MLP_FIRST_WAVEK_ROWS");
+    if (fw) h->first_wavek_rows = atoi(fw);
     const char *er = getenv("GNN_MLP_EVAL_ROWS");
     if (er) h->eval_rows_cap = atoi(er);
 }

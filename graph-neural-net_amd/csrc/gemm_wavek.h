@@ -31,14 +31,17 @@ static_assert(32 * WK_LDP <= WK_WAVE_FLOATS, "the partial tile reuses the wave's
 
 // (GNN_GEMM_HEAD_PARAMS, kernels.h: the main loop's first values preloaded into SGPRs.  HEAD = false: the struct's own copies --
 //  tools/gemm_probe 21 compares the two: 8.85 against 9.07 us forward, 10.0 against 10.2 backward at 256 x 1024 x 1024.)
-template <bool A_KC, bool B_KC, int EPI, int NW, int DEPTH, bool HEAD = true>
+// RAGGED (round 4): M and / or N need not be multiples of 32 (they are multiples of 16: 608 rows of a validation block, the 304
+// columns of a 300-wide layer).  Loads of rows past M and of columns past N are CLAMPED to the last row / the last float4 of the
+// row -- valid addresses whose products land in accumulator elements nobody stores -- and the epilogue guards its accesses.
+template <bool A_KC, bool B_KC, int EPI, int NW, int DEPTH, bool HEAD = true, bool RAGGED = false>
 __global__ __launch_bounds__(NW * 64) void gemm_f32_wavek_kernel(GNN_GEMM_HEAD_PARAMS(float), GemmParams p) {
     if constexpr (HEAD) GNN_GEMM_TAKE_HEAD(p);
     __shared__ __attribute__((aligned(16))) float lds[NW * WK_WAVE_FLOATS];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32; // M and N are multiples of 32 (checked by the host)
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32; // M and N are multiples of 32 (checked by the host) unless RAGGED
     float *sA = lds + wave * WK_WAVE_FLOATS, *sB = sA + WK_CH * WK_LDT;
 
     // this wave's chunks; K is a multiple of 16: the last chunk may be half a chunk ("tail")
@@ -55,20 +58,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_wavek_kernel(GNN_GEMM_HEAD_P
     // In a half chunk the pieces of k >= 16 are re-read from k - 16 (inside the operand) and zeroed before use.
     const float *a_src[4], *a_tail[4], *b_src[4], *b_tail[4];
     size_t a_step, b_step;
+    auto in_m = [&](int m) { return (RAGGED && m >= p.M) ? p.M - 1 : m; };   // (index of an A row / C row)
+    auto in_n = [&](int n) { return (RAGGED && n >= p.N) ? p.N - 1 : n; };   // (index of a B row when B is k-contiguous)
+    auto in_m4 = [&](int m) { return (RAGGED && m + 4 > p.M) ? p.M - 4 : m; }; // (first of four consecutive indices)
+    auto in_n4 = [&](int n) { return (RAGGED && n + 4 > p.N) ? p.N - 4 : n; };
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         if (A_KC) {
-            a_src[u] = p.A + (size_t)(m0 + 2 * fr + (u >> 1)) * p.lda + 8 * fq + 4 * (u & 1);
+            a_src[u] = p.A + (size_t)in_m(m0 + 2 * fr + (u >> 1)) * p.lda + 8 * fq + 4 * (u & 1);
             a_tail[u] = a_src[u] - (fq >= 2 ? 16 : 0);
         } else {
-            a_src[u] = p.A + (size_t)(8 * u + (lane >> 3)) * p.lda + m0 + 4 * (lane & 7);
+            a_src[u] = p.A + (size_t)(8 * u + (lane >> 3)) * p.lda + in_m4(m0 + 4 * (lane & 7));
             a_tail[u] = a_src[u] - (u >= 2 ? (size_t)16 * p.lda : 0);
         }
         if (B_KC) {
-            b_src[u] = p.B + (size_t)(n0 + 2 * fr + (u >> 1)) * p.ldb + 8 * fq + 4 * (u & 1);
+            b_src[u] = p.B + (size_t)in_n(n0 + 2 * fr + (u >> 1)) * p.ldb + 8 * fq + 4 * (u & 1);
             b_tail[u] = b_src[u] - (fq >= 2 ? 16 : 0);
         } else {
-            b_src[u] = p.B + (size_t)(8 * u + (lane >> 3)) * p.ldb + n0 + 4 * (lane & 7);
+            b_src[u] = p.B + (size_t)(8 * u + (lane >> 3)) * p.ldb + in_n4(n0 + 4 * (lane & 7));
             b_tail[u] = b_src[u] - (u >= 2 ? (size_t)16 * p.ldb : 0);
         }
     }
@@ -172,6 +179,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_wavek_kernel(GNN_GEMM_HEAD_P
     for (int w = 1; w < NW; w++) v += *reinterpret_cast<const f32x4 *>(&lds[w * WK_WAVE_FLOATS + row * WK_LDP + 4 * cq]);
 
     const int m = m0 + row, n = n0 + 4 * cq;
+    if (RAGGED && (m >= p.M || n >= p.N)) return; // (N is a multiple of 16: the four columns are all inside or all outside)
     const size_t off = (size_t)m * p.ldc + n;
     f32x4 out0, out1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 aux = {0.f, 0.f, 0.f, 0.f}, vold = aux, wold = aux;

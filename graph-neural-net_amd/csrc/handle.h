@@ -152,6 +152,7 @@ struct gnn_mlp {
     bool env_jit_off = false;  // GNN_MLP_JIT=0
     bool env_static_off = false; // GNN_MLP_STATIC=0
     bool env_chain_off = false;  // GNN_MLP_CHAIN=0: three launches per step (fwd_first / middle4 / grad_update)
+    int first_wavek_rows = 256;  // launch_fwd_first: blocks of at least this many rows take the (ragged) wave-K GEMM (GNN_MLP_FIRST_WAVEK_ROWS; 0 = never)
     int first_gemm_rows = 2048;  // launch_fwd_first: blocks of at least this many rows take gemm_f32_kernel (GNN_MLP_FIRST_GEMM_ROWS; 0 = never)
     bool env_rb_off = false;     // GNN_MLP_ROWBLOCK=0: middle4_kernel<.., SLABS> as the two-launch step's row-block kernel (round 2's form)
 };

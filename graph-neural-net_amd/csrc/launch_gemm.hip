@@ -30,6 +30,11 @@ template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm_wavek(gnn_mlp *h, int cls, const GemmParams &p) {
     launch_timed(h, cls, gemm_f32_wavek_kernel<A_KC, B_KC, EPI, 4, 2>, dim3(p.N / 32, p.M / 32), dim3(256), 0, GNN_GEMM_HEAD_ARGS(p), p);
 }
+// the ragged form (extents that are multiples of 16 only): forward products of a few hundred rows against a 300-wide layer
+template <bool A_KC, bool B_KC, int EPI>
+void launch_gemm_wavek_ragged(gnn_mlp *h, int cls, const GemmParams &p) {
+    launch_timed(h, cls, gemm_f32_wavek_kernel<A_KC, B_KC, EPI, 4, 2, true, true>, dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(256), 0, GNN_GEMM_HEAD_ARGS(p), p);
+}
 
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
@@ -171,6 +176,21 @@ void launch_fwd_first(gnn_mlp *h, const float *a0, int B) {
         p.m_true = B; p.n_true = h->dims[1];
         p.act = h->inner_act;
         launch_gemm<true, false, EPI_ACT>(h, GNN_K_FWD_GEMM0, p);
+        return;
+    }
+    // Blocks of a few hundred rows (the trainer's validation pass: 601 rows at MNIST's size, NNT:102-113): 16 x 16 tiles re-read
+    // their operand panels 4 FLOP per byte -- 722 workgroups moved 72 MB through L2 -> L1 for 283 MFLOP, 12.6 us
+    // (profiles/r04/observed_loop_kernel_stats.csv) -- where the wave-K kernel's 32 x 32 tiles (ragged form: 608 x 304) halve that.
+    if (h->first_wavek_rows > 0 && B_pad >= h->first_wavek_rows && !h->cur_idx && h->ld[0] >= 128 && !h->env_wavek_off) {
+        GemmParams p{};
+        p.A = a0; p.lda = h->ld[0];
+        p.B = h->W; p.ldb = h->ld[1];
+        p.C = h->act[1]; p.ldc = h->ld[1];
+        p.M = B_pad; p.N = h->ld[1]; p.K = h->ld[0];
+        p.m_true = B; p.n_true = h->dims[1];
+        p.act = h->inner_act;
+        if (wavek_fits(p.M, p.N, p.K)) launch_gemm_wavek<true, false, EPI_ACT>(h, GNN_K_FWD_GEMM0, p);
+        else launch_gemm_wavek_ragged<true, false, EPI_ACT>(h, GNN_K_FWD_GEMM0, p);
         return;
     }
     FwdFirstParams f{};

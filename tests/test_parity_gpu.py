@@ -960,3 +960,42 @@ def test_host_batch_steps_with_the_update_deferred(gnn, oracle_mod, monkeypatch)
     assert np.array_equal(a.get_momentum(), b.get_momentum())
     assert np.abs(a.get_weights() - ref.get_weights()).max() <= W_ATOL * steps
     assert np.abs(a.get_momentum() - ref.get_momentum()).max() <= W_ATOL * steps
+
+
+@pytest.mark.parametrize("dims,B,inner", [([784, 300, 100, 10], 601, LEAKY), ([784, 300, 100, 10], 264, SIGMOID),
+                                          ([200, 100, 50, 10], 300, TANH), ([784, 320, 100, 10], 1000, LEAKY)])
+def test_ragged_wave_k_first_layer(gnn, monkeypatch, dims, B, inner):
+    """Forward passes over a few hundred rows (validate(601 rows), NNT:102-113) take the wave-K GEMM for the first layer, in its
+    RAGGED form when the padded extents are not multiples of 32: 608 x 304 (N ragged), 272 x 304 (both), 304 x 112 with K = 208
+    (a half chunk at the end), and 1 008 x 320 (M ragged only).  Against the fp64 matrix form, and against the same handle
+    type with GNN_MLP_FIRST_WAVEK_ROWS=0 (fwd_first_kernel's 16 x 16 tiles: another summation order, so close, not equal);
+    labels wherever the margin allows."""
+    from tests import np_oracle
+    if os.environ.get("GNN_MLP_PATH") or os.environ.get("GNN_MLP_WAVEK") == "0":
+        pytest.skip("path forced by the environment")
+    X, Y = make_batch(dims, B, seed=77, sparse=True)
+    net = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    monkeypatch.setenv("GNN_MLP_FIRST_WAVEK_ROWS", "0")
+    old = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=inner, max_batch=B)
+    monkeypatch.delenv("GNN_MLP_FIRST_WAVEK_ROWS")
+    w = net.get_weights() * 0.3
+    net.set_weights(w); old.set_weights(w)
+    Ws = np_oracle.split(net.get_weights(), dims)
+    Z, pr = np_oracle.forward(Ws, X, inner)
+    p, po = net.propagate(X), old.propagate(X)
+    assert np.abs(p - pr).max() <= P_ATOL
+    assert np.abs(p - po).max() <= 1e-5
+    lr = np_oracle.loss(Ws, X, Y, inner)
+    l = net.calculateLoss(X, Y)
+    assert np.all(np.abs(l - lr) <= 2e-4 * np.abs(lr) + 2e-4)
+    clear = top2_margin(Z[-1]) > 1e-3
+    assert clear.sum() >= B - 10                    # (the tanh net at 0.3 x init has six near-ties in 300 rows)
+    assert np.array_equal(net.argmax(X)[clear], np.argmax(Z[-1], axis=1)[clear])
+    # the rows past B of the padded block and the columns past the layer's width must not leak: a smaller batch next
+    p2 = net.propagate(X[:257])
+    assert np.abs(p2 - pr[:257]).max() <= P_ATOL
+    # resident rows (the validation pass's form)
+    net.upload_dataset(X, Y)
+    hits = net.count_hits_range(0, B)
+    want = int((np.argmax(Z[-1], axis=1) == np.argmax(Y, axis=1)).sum())
+    assert abs(hits - want) <= int((~clear).sum())
