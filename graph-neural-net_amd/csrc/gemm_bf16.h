@@ -24,6 +24,18 @@
 #pragma once
 #include "kernels.h"
 
+// tools/gemm_probe defines GNN_GEMM_BF16_STAMPS: wave 0 of workgroup (0, 0) adds up the cycles between the marks of the main loop
+#ifdef GNN_GEMM_BF16_STAMPS
+__device__ unsigned long long gnn_bf16_stamps[16];
+#define GNN_STAMP_DECL unsigned long long st_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter(); const unsigned long long st_begin = st_prev
+#define GNN_STAMP(i) do { asm volatile("" ::: "memory"); const unsigned long long st_now = __builtin_readcyclecounter(); st_sum[i] += st_now - st_prev; st_prev = st_now; } while (0)
+#define GNN_STAMP_FLUSH do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { for (int i = 0; i < 9; i++) gnn_bf16_stamps[i] = st_sum[i]; gnn_bf16_stamps[9] = __builtin_readcyclecounter() - st_begin; } } while (0)
+#else
+#define GNN_STAMP_DECL
+#define GNN_STAMP(i)
+#define GNN_STAMP_FLUSH
+#endif
+
 namespace gnn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -69,27 +81,44 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16 *img, int ldt, int c0, in
 // With ONE 16-KB tile ahead (BK 64) the 512-row products of 4096-2048-2048-1024 ran at 11 B/clk/CU.
 template <int BM> struct GemmBf16Depth { static constexpr int BK = BM >= 128 ? 64 : BM >= 64 ? 128 : 256; };
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+// NSTG: 2 = one operand image in LDS, fragments one 32-k block ahead; 3 = TWO images (one barrier per tile, see the main loop),
+// every fragment of a tile requested up front; 4 = one image, fragments up front; 5 = two images, fragments one block ahead
+constexpr bool gemm_bf16_two_images(int nstg) { return nstg == 3 || nstg == 5; }
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTG = 2>
 constexpr size_t gemm_bf16_lds_bytes() {
-    constexpr int BK = GemmBf16Depth<BM>::BK, LDK = BK + 8;
+    constexpr int BK = GemmBf16Depth<BM>::BK, LDK = BK + 16;
     constexpr int LDTA = BM + ((BM / 16) % 2 == 0 ? 16 : 0), LDTB = BN + ((BN / 16) % 2 == 0 ? 16 : 0);
-    return sizeof(__bf16) * ((A_KC ? BM * LDK : BK * LDTA) + (B_KC ? BN * LDK : BK * LDTB));
+    return sizeof(__bf16) * ((A_KC ? BM * LDK : BK * LDTA) + (B_KC ? BN * LDK : BK * LDTB)) * (gemm_bf16_two_images(NSTG) ? 2 : 1);
 }
 
 // WM: wave rows (waves are WM x 2, WM * 128 threads); WM = 4 puts eight waves on a tile (see gemm_f32_kernel)
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int NSTG = 2, int WM = 2>
+// (tools/gemm_probe only: NSTG_ = NSTG + 10 x ablation -- 1: no global loads inside the loop, 2: no MFMAs, 3: no LDS reads, 4: no LDS writes)
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int NSTG_ = 2, int WM = 2>
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAMS(__bf16), GemmBf16Params p) {
     GNN_GEMM_TAKE_HEAD(p);
+    constexpr int NSTG = NSTG_ % 10, ABL = NSTG_ / 10;
     constexpr int NT = WM * 128;
     constexpr int BK = GemmBf16Depth<BM>::BK;
     constexpr int TM = BM / (WM * 16), TN = BN / 32; // 16x16 MFMA tiles per wave (waves are WM x 2)
-    constexpr int LDK = BK + 8;               // k-contiguous image: row stride = 4 banks (mod 64): 16 rows x 2 k-groups of a ds_read_b64 hit 64 banks once
+    // k-contiguous image [row][k]: a fragment is ONE ds_read_b128 -- lane (fr, fg) takes k = kk + 8 fg .. + 7 of row fr.  (Two
+    // ds_read_b64 per fragment, k = 4 fg + j and 16 + 4 fg + j at a row stride of BK + 8, were conflict-free as written -- and
+    // the compiler merges such a pair into ds_read2_b64, which the LDS serves in 16-lane groups over 32 banks at HALF the rate,
+    // where rows 8 apart collide: 16 LDS cycles per fragment instead of 4, and the multiplication of a tile ran at the LDS's
+    // pace, 1 040 cycles for 256 cycles of MFMAs -- tools/gemm_probe 34.)  ds_read_b128 is served in the 16-lane groups
+    // {0-3, 12-15, 20-27}, ... over 64 banks: a row stride of 8 banks mod 16 (BK + 16 elements = 72 or 40 banks) is conflict-free.
+    constexpr int LDK = BK + 16;
+    static_assert((LDK / 2) % 16 == 8, "row stride of the k-contiguous image: 8 banks mod 16");
+    // Mixed products (forward: A k-contiguous, W k-major) need BOTH operands to deal k to the slots alike: the k-major image is
+    // then written with its rows permuted inside every 32-k block -- k = 8 g + e sits in row 4 g + (e & 3) + 16 (e >> 2) -- so
+    // that the transpose reads (rows 4 fg + j and 16 + 4 fg + j, conflict-free) deliver k = 8 fg + e as well.
+    constexpr bool PERMUTE_KMAJOR = (A_KC != B_KC);
     // k-major image: row stride 32*odd bytes (BM = 128: 288 B, 64: 160 B, 32: 96 B)
     constexpr int LDTA = BM + ((BM / 16) % 2 == 0 ? 16 : 0), LDTB = BN + ((BN / 16) % 2 == 0 ? 16 : 0);
     constexpr int A_ELEMS = A_KC ? BM * LDK : BK * LDTA, B_ELEMS = B_KC ? BN * LDK : BK * LDTB;
     extern __shared__ __attribute__((aligned(16))) __bf16 gemm_bf16_smem[]; // up to 70 KB: dynamic (opt-in above 64 KB)
     __bf16 *As = gemm_bf16_smem, *Bs = gemm_bf16_smem + A_ELEMS;
-    static_assert(sizeof(__bf16) * (A_ELEMS + B_ELEMS) == gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC>(), "LDS size");
+    static_assert(sizeof(__bf16) * (A_ELEMS + B_ELEMS) * (gemm_bf16_two_images(NSTG) ? 2 : 1) == gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC, NSTG>(), "LDS size");
+    auto use_image = [&](int which) { As = gemm_bf16_smem + which * (A_ELEMS + B_ELEMS); Bs = As + A_ELEMS; }; // (NSTG == 3)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -153,18 +182,24 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAM
             rb[i] = v;
         }
     };
+    auto image_row = [](int k) { // row of a k-major image that holds k
+        if (!PERMUTE_KMAJOR) return k;
+        const int e = k & 7, g = (k >> 3) & 3;
+        return (k & ~31) + 4 * g + (e & 3) + 16 * (e >> 2);
+    };
     auto store_tiles = [&](const bf16x8 (&ra)[NA], const bf16x8 (&rb)[NB]) {
+        if constexpr (ABL == 4) { asm volatile("" ::"v"(ra[0]), "v"(rb[0])); return; }
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int c = t + i * NT;
             if (A_KC) *reinterpret_cast<bf16x8 *>(&As[(c / (BK / 8)) * LDK + (c % (BK / 8)) * 8]) = ra[i];
-            else *reinterpret_cast<bf16x8 *>(&As[(c / (BM / 8)) * LDTA + (c % (BM / 8)) * 8]) = ra[i];
+            else *reinterpret_cast<bf16x8 *>(&As[image_row(c / (BM / 8)) * LDTA + (c % (BM / 8)) * 8]) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             const int c = t + i * NT;
             if (B_KC) *reinterpret_cast<bf16x8 *>(&Bs[(c / (BK / 8)) * LDK + (c % (BK / 8)) * 8]) = rb[i];
-            else *reinterpret_cast<bf16x8 *>(&Bs[(c / (BN / 8)) * LDTB + (c % (BN / 8)) * 8]) = rb[i];
+            else *reinterpret_cast<bf16x8 *>(&Bs[image_row(c / (BN / 8)) * LDTB + (c % (BN / 8)) * 8]) = rb[i];
         }
     };
 
@@ -176,16 +211,23 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAM
 
     const int fr = lane & 15, fg = lane >> 4;
     // fragment of MFMA tile `tile` (16 rows / columns starting at r0) for the 32-wide k block at kk:
-    //   element j < 4: k = kk + 4 fg + j ; j >= 4: k = kk + 16 + 4 fg + (j - 4)
+    //   both operands k-major:   element j < 4: k = kk + 4 fg + j ; j >= 4: k = kk + 16 + 4 fg + (j - 4)
+    //   otherwise:               element j: k = kk + 8 fg + j
     auto frag_kc = [&](const __bf16 *img, int r0, int kk) {
-        const __bf16 *q = img + (r0 + fr) * LDK + kk + 4 * fg;
-        return join8(*reinterpret_cast<const s16x4 *>(q), *reinterpret_cast<const s16x4 *>(q + 16));
+        return *reinterpret_cast<const bf16x8 *>(img + (r0 + fr) * LDK + kk + 8 * fg);
     };
     auto frag_tr = [&](const __bf16 *img, int ldt, int c0, int kk) { return tr_frag(img, ldt, c0, kk, lane); };
 
     // Fragments of the NEXT 32-wide k block are read while this block's MFMAs issue (as in gemm_f32_kernel): a bf16 block is
     // only TM*TN MFMAs of 16 cycles, far less than an LDS round trip, and with one workgroup per CU nothing else covers it.
     auto read_block = [&](int kk, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
+        if constexpr (ABL == 3) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) a[i] = ra0[0];
+#pragma unroll
+            for (int j = 0; j < TN; j++) b[j] = rb0[0];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++)
             a[i] = A_KC ? frag_kc(As, wm * (TM * 16) + i * 16, kk) : frag_tr(As, LDTA, wm * (TM * 16) + i * 16, kk);
@@ -198,8 +240,11 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAM
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                if constexpr (ABL == 2) { acc[i][j][0] += (float)a[i][0]; acc[i][j][1] += (float)b[j][0]; }
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     };
+    constexpr int NBLK = BK / 32;
+    constexpr bool DEEP = NSTG == 3 || NSTG == 4; // (NSTG 4: the two-barrier loop with the deep fragment prefetch)
     auto multiply = [&](int k0) {
         const int kmax = (p.K - k0 < BK) ? p.K - k0 : BK; // K is a multiple of 16; rows past it were staged as zeros
         if (kmax < BK) { // ragged last tile: plain loop
@@ -207,6 +252,21 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAM
                 bf16x8 a[TM], b[TN];
                 read_block(kk, a, b);
                 mfma_block(a, b);
+            }
+            return;
+        }
+        if constexpr (DEEP) {
+            // every fragment of up to four blocks is requested before the first MFMA: the LDS serves the four waves' reads of a
+            // block in turn, a round trip of ~130 cycles where a block's MFMAs take 64, and with ONE block ahead every block
+            // waited for the difference
+            constexpr int G = NBLK < 4 ? NBLK : 4;
+#pragma unroll
+            for (int g0 = 0; g0 < NBLK; g0 += G) {
+                bf16x8 a[G][TM], b[G][TN];
+#pragma unroll
+                for (int g = 0; g < G; g++) read_block((g0 + g) * 32, a[g], b[g]);
+#pragma unroll
+                for (int g = 0; g < G; g++) mfma_block(a[g], b[g]);
             }
             return;
         }
@@ -227,23 +287,65 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAM
         }
     };
     auto main_loop = [&](auto inside) {
-        if constexpr (NSTG >= 2) {
+        if constexpr (gemm_bf16_two_images(NSTG)) {
+            // Two images in LDS, ONE barrier per tile: while image i & 1 is multiplied, tile i + 1 -- in registers since two tiles
+            // ago -- is written to the other image (nobody reads it: its last readers passed the barrier that ended tile i - 1),
+            // and the registers it frees take the loads of tile i + 3.
+            const int nt = (p.K + BK - 1) / BK;
             load_tiles(0, ra0, rb0, inside);
-            if (BK < p.K) load_tiles(BK, ra1, rb1, inside);
-            for (int k0 = 0; k0 < p.K; k0 += 2 * BK) { // two tiles per trip so that the stages keep their names
-                store_tiles(ra0, rb0);
-                __syncthreads();
-                if (k0 + 2 * BK < p.K) load_tiles(k0 + 2 * BK, ra0, rb0, inside);
-                multiply(k0);
-                __syncthreads();
-                if (k0 + BK < p.K) {
+            if (nt > 1) load_tiles(BK, ra1, rb1, inside);
+            use_image(0);
+            store_tiles(ra0, rb0);
+            if (nt > 2) load_tiles(2 * BK, ra0, rb0, inside);
+            __syncthreads();
+            for (int i = 0; i < nt; i += 2) { // two tiles per trip so that the stages keep their names
+                if (i + 1 < nt) {
+                    use_image(1);
                     store_tiles(ra1, rb1);
-                    __syncthreads();
-                    if (k0 + 3 * BK < p.K) load_tiles(k0 + 3 * BK, ra1, rb1, inside);
-                    multiply(k0 + BK);
+                    if (i + 3 < nt) load_tiles((i + 3) * BK, ra1, rb1, inside);
+                }
+                use_image(0);
+                multiply(i * BK);
+                __syncthreads();
+                if (i + 1 < nt) {
+                    if (i + 2 < nt) {
+                        use_image(0);
+                        store_tiles(ra0, rb0);
+                        if (i + 4 < nt) load_tiles((i + 4) * BK, ra0, rb0, inside);
+                    }
+                    use_image(1);
+                    multiply((i + 1) * BK);
                     __syncthreads();
                 }
             }
+        } else if constexpr (NSTG >= 2) {
+            GNN_STAMP_DECL;
+            load_tiles(0, ra0, rb0, inside);
+            if (BK < p.K) load_tiles(BK, ra1, rb1, inside);
+            for (int k0 = 0; k0 < p.K; k0 += 2 * BK) { // two tiles per trip so that the stages keep their names
+                GNN_STAMP(0);
+                store_tiles(ra0, rb0);
+                GNN_STAMP(1);
+                __syncthreads();
+                GNN_STAMP(2);
+                if (k0 + 2 * BK < p.K && ABL != 1) load_tiles(k0 + 2 * BK, ra0, rb0, inside);
+                multiply(k0);
+                GNN_STAMP(3);
+                __syncthreads();
+                GNN_STAMP(4);
+                if (k0 + BK < p.K) {
+                    store_tiles(ra1, rb1);
+                    GNN_STAMP(5);
+                    __syncthreads();
+                    GNN_STAMP(6);
+                    if (k0 + 3 * BK < p.K && ABL != 1) load_tiles(k0 + 3 * BK, ra1, rb1, inside);
+                    multiply(k0 + BK);
+                    GNN_STAMP(7);
+                    __syncthreads();
+                    GNN_STAMP(8);
+                }
+            }
+            GNN_STAMP_FLUSH;
         } else {
             load_tiles(0, ra0, rb0, inside);
             for (int k0 = 0; k0 < p.K; k0 += BK) {
@@ -265,7 +367,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAM
     // private LDS area and handles it as 16-B pieces: lane -> (row, 4 consecutive columns), 256-B runs per row.
     constexpr int EW = TN * 16, ELD = EW + 4, C4 = EW / 4, RPP = 64 / C4, PASSES = 16 / RPP; // float4s per row, rows per pass
     float *est = reinterpret_cast<float *>(gemm_bf16_smem) + wave * (16 * ELD);
-    static_assert(2 * WM * 16 * ELD * sizeof(float) <= gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC>(), "epilogue staging fits the operand images");
+    static_assert(2 * WM * 16 * ELD * sizeof(float) <= gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC, NSTG>(), "epilogue staging fits the operand images");
     const int erow = lane / C4, ec4 = lane % C4;
 #pragma unroll
     for (int i = 0; i < TM; i++) {

@@ -8,18 +8,18 @@ namespace gnn {
 namespace host {
 
 // bf16 operands (gemm_bf16.h): the same tile choice; 128x128 tiles only when they alone fill the chip
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2, int NSTG = 2>
 void launch_gemm_bf16_t(gnn_mlp *h, int cls, const GemmBf16Params &p) {
-    constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC>();
+    constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC, NSTG>();
     static bool opted_in = false; // more than 64 KB of dynamic LDS needs the opt-in, once per instantiation
     if (!opted_in) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, 2, WM>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, NSTG, WM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             if (h->launch_error == hipSuccess) h->launch_error = hipGetLastError();
         }
         opted_in = true;
     }
-    launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, 2, WM>, dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(WM * 128), lds, GNN_GEMM_HEAD_ARGS(p), p);
+    launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, NSTG, WM>, dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(WM * 128), lds, GNN_GEMM_HEAD_ARGS(p), p);
 }
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
@@ -31,20 +31,25 @@ void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
     // keep more of it in flight: 4096 x 2048 x 512 with the update 41.5 us on 128 x 128 tiles (one workgroup per CU at its
     // register count), 32.4 us on 64 x 64 (profiles/r02/gemm_probe_bf16_interior.log)
     if (tile == 128 && !A_KC && !B_KC && EPI == EPI_SGD) tile = 64;
+    // Main-loop forms (gemm_bf16.h, NSTG; profiles/r04/gemm_probe_bf16_main_loop_forms.log, configs[3]'s products): TWO operand
+    // images in LDS and one barrier per tile (5) with eight waves on a 64 x 64 tile is 15-22 % faster than one image (2) on the
+    // forward and backward-data products (512 x 2048 x 4096: 24.8 -> 20.5 us; backward 512 x 2048 x 2048: 15.3 -> 11.9 -- which
+    // was 18.5 before the k-contiguous image moved to one ds_read_b128 per fragment), 4-7 % on the two smaller gradient +
+    // update products, and even on the largest (2 048 tiles, bound by the masters' traffic).
+    constexpr bool fwd_or_bwd = A_KC;
+    const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
     // a forward product whose 64 x 64 grid is 128..255 tiles (the 512 x 1024 logits of configs[3]: 128) leaves half the chip
-    // without a workgroup: 32 x 64 tiles, twice as many, 13.2 -> 10.1 us there.  Every other shape tried in round 4 -- 64 x 32,
-    // 32 x 64, 32 x 32, 128 x 64 on the backward-data, forward-2 and gradient + update products -- is 5-45 % SLOWER than the
-    // shipped 64 x 64 (profiles/r04/gemm_probe_bf16_tile_shapes.log).
+    // without a workgroup: 32 x 64 tiles, twice as many, 13.2 -> 10.1 us there (9.3 with two images).  Every other shape tried in
+    // round 4 -- 64 x 32, 32 x 64, 32 x 32, 128 x 64 on the backward-data, forward-2 and gradient + update products -- is 5-45 %
+    // SLOWER than 64 x 64 (profiles/r04/gemm_probe_bf16_tile_shapes.log).
     if constexpr (A_KC && !B_KC) {
-        const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
-        if (tile == 64 && t64 < 256 && p.M % 32 == 0) { launch_gemm_bf16_t<32, 64, A_KC, B_KC, EPI>(h, cls, p); return; }
+        if (tile == 64 && t64 < 256 && p.M % 32 == 0) { launch_gemm_bf16_t<32, 64, A_KC, B_KC, EPI, 2, 5>(h, cls, p); return; }
     }
     switch (tile) {
     case 128: launch_gemm_bf16_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;
     case 64:
-        // the forward form gains ~6 % from eight waves on the tile (512 x 2048 x 4096: 28.0 -> 26.3 us); backward data loses
-        // 3-10 %, the gradient form is even (profiles/r02/gemm_probe_bf16_waves.log)
-        if constexpr (A_KC && !B_KC) launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI, 4>(h, cls, p);
+        if constexpr (fwd_or_bwd) launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI, 4, 5>(h, cls, p);
+        else if (t64 <= 1024) launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI, 4, 5>(h, cls, p);
         else launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI>(h, cls, p);
         break;
     default: launch_gemm_bf16_t<32, 32, A_KC, B_KC, EPI>(h, cls, p); break;

@@ -1,6 +1,7 @@
 // gemm_probe.hip -- development harness (not shipped): times gemm_f32_kernel instantiations (tile, waves, register
 // stages) on the GEMM shapes of BASELINE configs[3] (4096-2048-2048-1024, 512 rows) and configs[4]
 // (784-1024-1024-1024-10, 256 rows).  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip -o tools/gemm_probe
+#define GNN_GEMM_BF16_STAMPS
 #include "../graph-neural-net_amd/csrc/gemm_wavek.h"
 #include "../graph-neural-net_amd/csrc/gemm_bf16.h"
 #include <cstdio>
@@ -95,7 +96,7 @@ void runb(const char *what, int M, int N, int K) {
     p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
     p.aux = dW; p.ldaux = N + g_pad; p.W = dW; p.V = dV; p.Wb = reinterpret_cast<__bf16 *>(dAux); p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
     if (EPI == EPI_SGD) { p.C = nullptr; p.Cb = nullptr; }
-    constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, AK, BKC>();
+    constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, AK, BKC, NSTG % 10>();
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, AK, BKC, EPI, NSTG, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(WM * 128);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -107,6 +108,13 @@ void runb(const char *what, int M, int N, int K) {
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    if (getenv("GEMM_PROBE_STAMPS") && (NSTG % 10 == 2 || NSTG % 10 == 4)) {
+        unsigned long long st[16];
+        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(gnn_bf16_stamps), sizeof(st)));
+        const double steps = (double)((K + GemmBf16Depth<BM>::BK - 1) / GemmBf16Depth<BM>::BK);
+        printf("    cycles per tile of K (wave 0 of workgroup 0; %d tiles): write image (waits for its loads) %.0f | barrier %.0f | issue loads + multiply %.0f | barrier %.0f | loop top %.0f   (whole loop: %.0f per tile)\n", (int)steps,
+               (st[1] + st[5]) / steps, (st[2] + st[6]) / steps, (st[3] + st[7]) / steps, (st[4] + st[8]) / steps, st[0] / steps, st[9] / steps);
+    }
     printf("%-34s %4dx%4dx%4d  bf16 tile %3dx%-3d stages %d waves %d  %8.2f us  %6.1f TFLOP/s (%4.1f %% of 2500)  %d tiles\n", what, M, N, K, BM, BN, NSTG, WM * 2, us, tf, 100.0 * tf / 2500.0,
            (int)(grid.x * grid.y));
     fflush(stdout);
@@ -178,6 +186,105 @@ int main(int argc, char **argv) {
             runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 2", 2048, 1024, 512);
             runb<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 2", 2048, 1024, 512);
         }
+        return 0;
+    }
+    if (which == 32) {
+        printf("---- round 4: what ONE K-slice of a split-K product would cost (256 workgroups of a large tile, each over K / S) against the shipped 64 x 64 tiles over all of K\n");
+        for (int rep = 0; rep < 2; rep++) {
+            runb<64, 64, true, false, EPI_ACT, 2, 4>("forward 1 (shipped)", 512, 2048, 4096);
+            runb<128, 128, true, false, EPI_ACT, 2, 2>("forward 1: 64 tiles x 4 slices as", 2048, 2048, 1024);
+            runb<128, 128, true, false, EPI_ACT, 2, 4>("forward 1: 64 tiles x 4 slices as", 2048, 2048, 1024);
+            runb<128, 64, true, false, EPI_ACT, 2, 2>("forward 1: 128 tiles x 2 slices as", 1024, 2048, 2048);
+            runb<128, 64, true, false, EPI_ACT, 2, 4>("forward 1: 128 tiles x 2 slices as", 1024, 2048, 2048);
+            runb<64, 64, true, false, EPI_ACT, 2, 4>("forward 2 (shipped)", 512, 2048, 2048);
+            runb<128, 128, true, false, EPI_ACT, 2, 2>("forward 2: 64 tiles x 4 slices as", 2048, 2048, 512);
+            runb<128, 64, true, false, EPI_ACT, 2, 2>("forward 2: 128 tiles x 2 slices as", 1024, 2048, 1024);
+            runb<64, 64, true, true, EPI_DACT, 2, 2>("backward data 1 (shipped)", 512, 2048, 2048);
+            runb<128, 128, true, true, EPI_DACT, 2, 2>("backward data 1: 64 x 4 as", 2048, 2048, 512);
+            runb<128, 64, true, true, EPI_DACT, 2, 2>("backward data 1: 128 x 2 as", 1024, 2048, 1024);
+            runb<128, 128, true, false, EPI_ACT, 2, 2>("(one slice alone: 64 workgroups)", 512, 2048, 1024);
+        }
+        return 0;
+    }
+    if (which == 33) {
+        printf("---- round 4: two LDS images and one barrier per tile (stages 3) against the shipped main loop (stages 2)\n");
+        for (int rep = 0; rep < 2; rep++) {
+            runb<64, 64, true, false, EPI_ACT, 2, 4>("forward 1 (shipped)", 512, 2048, 4096);
+            runb<64, 64, true, false, EPI_ACT, 3, 4>("forward 1", 512, 2048, 4096);
+            runb<64, 64, true, false, EPI_ACT, 3, 2>("forward 1", 512, 2048, 4096);
+            runb<64, 64, true, false, EPI_ACT, 2, 4>("forward 2 (shipped)", 512, 2048, 2048);
+            runb<64, 64, true, false, EPI_ACT, 3, 4>("forward 2", 512, 2048, 2048);
+            runb<64, 64, true, false, EPI_ACT, 3, 2>("forward 2", 512, 2048, 2048);
+            runb<32, 64, true, false, EPI_STORE, 2, 2>("logits (shipped)", 512, 1024, 2048);
+            runb<32, 64, true, false, EPI_STORE, 3, 2>("logits", 512, 1024, 2048);
+            runb<64, 64, true, true, EPI_DACT, 2, 2>("backward data 2 (shipped)", 512, 2048, 1024);
+            runb<64, 64, true, true, EPI_DACT, 3, 2>("backward data 2", 512, 2048, 1024);
+            runb<64, 64, true, true, EPI_DACT, 3, 4>("backward data 2", 512, 2048, 1024);
+            runb<64, 64, true, true, EPI_DACT, 2, 2>("backward data 1 (shipped)", 512, 2048, 2048);
+            runb<64, 64, true, true, EPI_DACT, 3, 2>("backward data 1", 512, 2048, 2048);
+            runb<64, 64, true, true, EPI_DACT, 3, 4>("backward data 1", 512, 2048, 2048);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 0 (shipped)", 4096, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 3, 2>("gradient + update 0", 4096, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 1 (shipped)", 2048, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 3, 2>("gradient + update 1", 2048, 2048, 512);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 2 (shipped)", 2048, 1024, 512);
+            runb<64, 64, false, false, EPI_SGD, 3, 2>("gradient + update 2", 2048, 1024, 512);
+            runb<128, 128, true, false, EPI_ACT, 3, 2>("forward 1: 64 tiles x 4 slices as", 2048, 2048, 1024);
+            runb<128, 128, true, false, EPI_ACT, 3, 4>("forward 1: 64 tiles x 4 slices as", 2048, 2048, 1024);
+            runb<128, 128, true, true, EPI_DACT, 3, 2>("backward data 1: 64 x 4 as", 2048, 2048, 512);
+        }
+        return 0;
+    }
+    if (which == 34) {
+        printf("---- round 4: where the cycles of the shipped bf16 main loop go (GEMM_PROBE_STAMPS=1; GEMM_PROBE_MODE=1: no global loads in the loop, 2: no MFMAs)\n");
+
+        runb<64, 64, true, false, EPI_ACT, 2, 4>("forward 1 (shipped)", 512, 2048, 4096);
+        runb<64, 64, true, false, EPI_ACT, 4, 4>("forward 1, deep fragment prefetch", 512, 2048, 4096);
+        runb<64, 64, true, false, EPI_ACT, 2, 2>("forward 1", 512, 2048, 4096);
+        runb<64, 64, true, false, EPI_ACT, 4, 2>("forward 1, deep fragment prefetch", 512, 2048, 4096);
+        runb<64, 64, true, false, EPI_ACT, 2, 4>("forward 2 (shipped)", 512, 2048, 2048);
+        runb<64, 64, true, true, EPI_DACT, 2, 2>("backward data 1 (shipped)", 512, 2048, 2048);
+        runb<64, 64, true, true, EPI_DACT, 4, 2>("backward data 1, deep fragment prefetch", 512, 2048, 2048);
+        runb<64, 64, true, true, EPI_DACT, 2, 4>("backward data 1", 512, 2048, 2048);
+        runb<64, 64, true, true, EPI_DACT, 4, 4>("backward data 1, deep fragment prefetch", 512, 2048, 2048);
+        runb<64, 64, false, false, EPI_SGD, 4, 2>("gradient + update 0, deep fragment prefetch", 4096, 2048, 512);
+        runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 0 (shipped)", 4096, 2048, 512);
+        runb<128, 128, true, false, EPI_ACT, 2, 2>("forward 1: 64 tiles x 4 slices as", 2048, 2048, 1024);
+        runb<128, 128, true, false, EPI_ACT, 2, 2>("(one slice alone: 64 workgroups)", 512, 2048, 1024);
+        runb<128, 128, true, true, EPI_DACT, 2, 2>("backward data 1: 64 x 4 as", 2048, 2048, 512);
+        return 0;
+    }
+    if (which == 35) {
+        printf("---- round 4: main-loop forms of the bf16 GEMM (stages 2 = shipped before; 3 = two LDS images + all fragments of a tile up front; 4 = one image, fragments up front; 5 = two images, one block ahead)\n");
+        for (int rep = 0; rep < 2; rep++) {
+#define FORMS(name, BM_, BN_, AK, BKC, EPI, M, N, K) \
+            runb<BM_, BN_, AK, BKC, EPI, 2, 2>(name, M, N, K); runb<BM_, BN_, AK, BKC, EPI, 2, 4>(name, M, N, K); \
+            runb<BM_, BN_, AK, BKC, EPI, 3, 2>(name, M, N, K); runb<BM_, BN_, AK, BKC, EPI, 3, 4>(name, M, N, K); \
+            runb<BM_, BN_, AK, BKC, EPI, 4, 2>(name, M, N, K); runb<BM_, BN_, AK, BKC, EPI, 4, 4>(name, M, N, K); \
+            runb<BM_, BN_, AK, BKC, EPI, 5, 2>(name, M, N, K); runb<BM_, BN_, AK, BKC, EPI, 5, 4>(name, M, N, K);
+            FORMS("forward 1", 64, 64, true, false, EPI_ACT, 512, 2048, 4096)
+            FORMS("forward 2", 64, 64, true, false, EPI_ACT, 512, 2048, 2048)
+            FORMS("backward data 2", 64, 64, true, true, EPI_DACT, 512, 2048, 1024)
+            FORMS("backward data 1", 64, 64, true, true, EPI_DACT, 512, 2048, 2048)
+            FORMS("gradient + update 0", 64, 64, false, false, EPI_SGD, 4096, 2048, 512)
+            FORMS("gradient + update 1", 64, 64, false, false, EPI_SGD, 2048, 2048, 512)
+            FORMS("gradient + update 2", 64, 64, false, false, EPI_SGD, 2048, 1024, 512)
+            runb<32, 64, true, false, EPI_STORE, 2, 2>("logits", 512, 1024, 2048);
+            runb<32, 64, true, false, EPI_STORE, 3, 2>("logits", 512, 1024, 2048);
+            runb<32, 64, true, false, EPI_STORE, 4, 2>("logits", 512, 1024, 2048);
+            runb<32, 64, true, false, EPI_STORE, 5, 2>("logits", 512, 1024, 2048);
+            runb<64, 64, true, false, EPI_STORE, 3, 4>("logits", 512, 1024, 2048);
+        }
+        return 0;
+    }
+    if (which == 36) {
+        printf("---- round 4: ablations of the bf16 main loop (stages 2; 12: no global loads inside the loop, 22: no MFMAs, 32: no LDS reads, 42: no LDS writes)\n");
+#define ABLS(name, BM_, BN_, AK, BKC, EPI, WM_, M, N, K) \
+        runb<BM_, BN_, AK, BKC, EPI, 2, WM_>(name, M, N, K); runb<BM_, BN_, AK, BKC, EPI, 12, WM_>(name, M, N, K); runb<BM_, BN_, AK, BKC, EPI, 22, WM_>(name, M, N, K); \
+        runb<BM_, BN_, AK, BKC, EPI, 32, WM_>(name, M, N, K); runb<BM_, BN_, AK, BKC, EPI, 42, WM_>(name, M, N, K);
+        ABLS("forward 1", 64, 64, true, false, EPI_ACT, 2, 512, 2048, 4096)
+        ABLS("forward 1", 64, 64, true, false, EPI_ACT, 4, 512, 2048, 4096)
+        ABLS("backward data 1", 64, 64, true, true, EPI_DACT, 2, 512, 2048, 2048)
         return 0;
     }
     if (which == 31) {
