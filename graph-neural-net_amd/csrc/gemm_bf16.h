@@ -74,6 +74,71 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16 *img, int ldt, int c0, in
     return join8(lo, hi);
 }
 
+// ---- epilogue (shared by gemm_bf16_kernel and gemm_bf16_dma_kernel) ------------------------------------
+// acc[i][j]: the 16 x 16 MFMA tile at rows m0 + wm * (TM * 16) + i * 16, columns n0 + wn * (TN * 16) + j * 16.  `smem`: LDS the
+// waves may overwrite (every wave is past its last operand read): 2 * WM * 16 * (TN * 16 + 4) floats.
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void gemm_bf16_epilogue(f32x4 (&acc)[TM][TN], const GemmBf16Params &p, float *smem, int m0, int n0, int wave, int lane) {
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    // The accumulator of a 16x16 MFMA tile has its column on the lane (lane & 15) and four rows in the registers:
+    // stored as it stands that is 4 B per lane (64-B segments; W, V, Wb of the update: five such accesses per
+    // element).  Each wave therefore turns one row of its MFMA tiles (16 rows x TN*16 columns) at a time through a
+    // private LDS area and handles it as 16-B pieces: lane -> (row, 4 consecutive columns), 256-B runs per row.
+    constexpr int EW = TN * 16, ELD = EW + 4, C4 = EW / 4, RPP = 64 / C4, PASSES = 16 / RPP; // float4s per row, rows per pass
+    float *est = smem + wave * (16 * ELD);
+    const int erow = lane / C4, ec4 = lane % C4;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) est[(fg * 4 + r) * ELD + j * 16 + fr] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier(); // one wave, LDS operations complete in order: a scheduling fence is enough
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
+            const int row = ps * RPP + erow;
+            const int m = m0 + wm * (TM * 16) + i * 16 + row;
+            const int n = n0 + wn * EW + ec4 * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(est + row * ELD + ec4 * 4);
+            if (m < p.M && n < p.N) { // N is a multiple of 16: the four columns are all inside or all outside
+                const size_t off = (size_t)m * p.ldc + n;
+                f32x4 out = {0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_SGD) { // on the f32 masters, SCE:333; the bf16 shadow follows the master
+                    f32x4 w = *reinterpret_cast<const f32x4 *>(p.W + off);
+                    f32x4 vv = *reinterpret_cast<const f32x4 *>(p.V + off);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (m < p.m_true && n + e < p.n_true) {
+                            const float adj = sgd_adj(p.step_over_b, v[e], p.momentum, vv[e]);
+                            w[e] -= adj;
+                            vv[e] = adj;
+                        }
+                    }
+                    *reinterpret_cast<f32x4 *>(p.W + off) = w;
+                    *reinterpret_cast<f32x4 *>(p.V + off) = vv;
+                    *reinterpret_cast<bf16x4 *>(p.Wb + off) = (bf16x4){(__bf16)w[0], (__bf16)w[1], (__bf16)w[2], (__bf16)w[3]};
+                } else {
+                    f32x4 aux = {0.f, 0.f, 0.f, 0.f};
+                    if (EPI == EPI_DACT) aux = *reinterpret_cast<const f32x4 *>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const bool live = (m < p.m_true) && (n + e < p.n_true);
+                        if (EPI == EPI_STORE) out[e] = live ? v[e] : 0.f;
+                        else if (EPI == EPI_ACT) out[e] = live ? act_fn(p.act, v[e]) : 0.f;
+                        else out[e] = live ? v[e] * act_prime_from_a(p.act, aux[e]) : 0.f;
+                    }
+                    if (p.C) *reinterpret_cast<f32x4 *>(p.C + off) = out;
+                    if (p.Cb) *reinterpret_cast<bf16x4 *>(p.Cb + off) = (bf16x4){(__bf16)out[0], (__bf16)out[1], (__bf16)out[2], (__bf16)out[3]};
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // K depth of one staged tile.  A 4-wave workgroup keeps TWO tiles ahead in registers while it multiplies the
 // staged one (the loads of tile t+2 are issued before tile t is multiplied); with one workgroup per CU (grids
 // of 256..511 tiles) that is all the CU has in flight, and it must cover a memory round trip (~1 500 cycles
@@ -360,64 +425,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAM
     if (interior) main_loop(BoolC<true>{});
     else main_loop(BoolC<false>{});
 
-    // ---- epilogue ------------------------------------------------------------------------------------
-    // The accumulator of a 16x16 MFMA tile has its column on the lane (lane & 15) and four rows in the registers:
-    // stored as it stands that is 4 B per lane (64-B segments; W, V, Wb of the update: five such accesses per
-    // element).  Each wave therefore turns one row of its MFMA tiles (16 rows x TN*16 columns) at a time through a
-    // private LDS area and handles it as 16-B pieces: lane -> (row, 4 consecutive columns), 256-B runs per row.
-    constexpr int EW = TN * 16, ELD = EW + 4, C4 = EW / 4, RPP = 64 / C4, PASSES = 16 / RPP; // float4s per row, rows per pass
-    float *est = reinterpret_cast<float *>(gemm_bf16_smem) + wave * (16 * ELD);
-    static_assert(2 * WM * 16 * ELD * sizeof(float) <= gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC, NSTG>(), "epilogue staging fits the operand images");
-    const int erow = lane / C4, ec4 = lane % C4;
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) est[(fg * 4 + r) * ELD + j * 16 + fr] = acc[i][j][r];
-        __builtin_amdgcn_wave_barrier(); // one wave, LDS operations complete in order: a scheduling fence is enough
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ps++) {
-            const int row = ps * RPP + erow;
-            const int m = m0 + wm * (TM * 16) + i * 16 + row;
-            const int n = n0 + wn * EW + ec4 * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(est + row * ELD + ec4 * 4);
-            if (m < p.M && n < p.N) { // N is a multiple of 16: the four columns are all inside or all outside
-                const size_t off = (size_t)m * p.ldc + n;
-                f32x4 out = {0.f, 0.f, 0.f, 0.f};
-                if (EPI == EPI_SGD) { // on the f32 masters, SCE:333; the bf16 shadow follows the master
-                    f32x4 w = *reinterpret_cast<const f32x4 *>(p.W + off);
-                    f32x4 vv = *reinterpret_cast<const f32x4 *>(p.V + off);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        if (m < p.m_true && n + e < p.n_true) {
-                            const float adj = sgd_adj(p.step_over_b, v[e], p.momentum, vv[e]);
-                            w[e] -= adj;
-                            vv[e] = adj;
-                        }
-                    }
-                    *reinterpret_cast<f32x4 *>(p.W + off) = w;
-                    *reinterpret_cast<f32x4 *>(p.V + off) = vv;
-                    *reinterpret_cast<bf16x4 *>(p.Wb + off) = (bf16x4){(__bf16)w[0], (__bf16)w[1], (__bf16)w[2], (__bf16)w[3]};
-                } else {
-                    f32x4 aux = {0.f, 0.f, 0.f, 0.f};
-                    if (EPI == EPI_DACT) aux = *reinterpret_cast<const f32x4 *>(p.aux + (size_t)m * p.ldaux + n);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const bool live = (m < p.m_true) && (n + e < p.n_true);
-                        if (EPI == EPI_STORE) out[e] = live ? v[e] : 0.f;
-                        else if (EPI == EPI_ACT) out[e] = live ? act_fn(p.act, v[e]) : 0.f;
-                        else out[e] = live ? v[e] * act_prime_from_a(p.act, aux[e]) : 0.f;
-                    }
-                    if (p.C) *reinterpret_cast<f32x4 *>(p.C + off) = out;
-                    if (p.Cb) *reinterpret_cast<bf16x4 *>(p.Cb + off) = (bf16x4){(__bf16)out[0], (__bf16)out[1], (__bf16)out[2], (__bf16)out[3]};
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    static_assert(2 * WM * 16 * (TN * 16 + 4) * sizeof(float) <= gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC, NSTG>(), "epilogue staging fits the operand images");
+    gemm_bf16_epilogue<TM, TN, EPI>(acc, p, reinterpret_cast<float *>(gemm_bf16_smem), m0, n0, wave, lane);
 }
 
 // f32 -> bf16 (RNE) over a flat buffer: the shadow of W after set_weights / init / load, dataset rows, ...

@@ -1,5 +1,6 @@
 // launch_bf16.hip -- host side of GNN_DTYPE_BF16's per-layer GEMMs (gemm_bf16.h).
 #include "handle.h"
+#include "gemm_bf16_dma.h"
 
 using namespace gnn;
 using namespace gnn::host;
@@ -20,6 +21,22 @@ void launch_gemm_bf16_t(gnn_mlp *h, int cls, const GemmBf16Params &p) {
         opted_in = true;
     }
     launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, NSTG, WM>, dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(WM * 128), lds, GNN_GEMM_HEAD_ARGS(p), p);
+}
+// the DMA form (gemm_bf16_dma.h): whole tiles only
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM, int NIMG>
+bool launch_gemm_bf16_dma_t(gnn_mlp *h, int cls, const GemmBf16Params &p) {
+    if (h->env_bf16_dma_off || p.M % BM || p.N % BN || p.K % GemmBf16Depth<BM>::BK) return false;
+    constexpr size_t lds = gemm_bf16_dma_lds_bytes<BM, BN, NIMG>();
+    auto kern = gemm_bf16_dma_kernel<BM, BN, A_KC, B_KC, EPI, WM, NIMG>;
+    static bool opted_in = false;
+    if (!opted_in) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            if (h->launch_error == hipSuccess) h->launch_error = hipGetLastError();
+        }
+        opted_in = true;
+    }
+    launch_timed(h, cls, kern, dim3(p.N / BN, p.M / BM), dim3(WM * 128), lds, GNN_GEMM_HEAD_ARGS(p), p);
+    return true;
 }
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
@@ -42,8 +59,26 @@ void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
     // without a workgroup: 32 x 64 tiles, twice as many, 13.2 -> 10.1 us there (9.3 with two images).  Every other shape tried in
     // round 4 -- 64 x 32, 32 x 64, 32 x 32, 128 x 64 on the backward-data, forward-2 and gradient + update products -- is 5-45 %
     // SLOWER than 64 x 64 (profiles/r04/gemm_probe_bf16_tile_shapes.log).
+    // Operand tiles by LDS DMA (gemm_bf16_dma.h; whole tiles only): three images and two tiles in flight for the long products,
+    // two images where a second workgroup per CU matters more (the gradient + update products, whose epilogue moves the masters)
+    // or K is short.  profiles/r04/gemm_probe_bf16_dma.log, against the two-image register-staged form: 512 x 2048 x 4096
+    // 20.8 -> 16.9 us, backward 512 x 2048 x 2048 11.9 -> 10.7, the 512 x 1024 logits 9.6 -> 8.0, gradient + update
+    // 2048 x 1024 x 512 11.3 -> 9.6; 4096 x 2048 x 2048 on 128 x 128 tiles 501 -> 717 TFLOP/s.
+    const int nt = p.K / 128;
     if constexpr (A_KC && !B_KC) {
-        if (tile == 64 && t64 < 256 && p.M % 32 == 0) { launch_gemm_bf16_t<32, 64, A_KC, B_KC, EPI, 2, 5>(h, cls, p); return; }
+        if (tile == 64 && t64 < 256 && p.M % 32 == 0) {
+            if (launch_gemm_bf16_dma_t<32, 64, A_KC, B_KC, EPI, 2, 2>(h, cls, p)) return;
+            launch_gemm_bf16_t<32, 64, A_KC, B_KC, EPI, 2, 5>(h, cls, p);
+            return;
+        }
+    }
+    if (tile == 128 && launch_gemm_bf16_dma_t<128, 128, A_KC, B_KC, EPI, 4, 3>(h, cls, p)) return;
+    if (tile == 64) {
+        if constexpr (fwd_or_bwd) {
+            if (nt >= 16 ? launch_gemm_bf16_dma_t<64, 64, A_KC, B_KC, EPI, 4, 3>(h, cls, p) : launch_gemm_bf16_dma_t<64, 64, A_KC, B_KC, EPI, 4, 2>(h, cls, p)) return;
+        } else {
+            if (launch_gemm_bf16_dma_t<64, 64, A_KC, B_KC, EPI, 4, 2>(h, cls, p)) return;
+        }
     }
     switch (tile) {
     case 128: launch_gemm_bf16_t<128, 128, A_KC, B_KC, EPI>(h, cls, p); break;

@@ -155,3 +155,42 @@ def test_bf16_rowblock_kernel_against_middle4(gnn, monkeypatch, dims, B, inner):
     assert np.abs(old.get_weights() - w).max() <= bound, (scatter, bound)
     assert np.abs(new.get_weights() - old.get_weights()).max() <= 2 * bound   # (each is within `bound` of the oracle)
     assert np.mean(np.abs(new.get_weights() - w)) <= 2e-5
+
+
+@pytest.mark.parametrize("dims,B", [([512, 1024, 1024, 512], 512), ([4096, 2048, 2048, 1024], 512), ([256, 2048, 2048, 16], 2048)])
+def test_bf16_dma_form_equals_register_staged(gnn, monkeypatch, dims, B):
+    """Whole-tile products take gemm_bf16_dma_kernel (operand tiles by LDS DMA into permuted images, gemm_bf16_dma.h);
+    GNN_MLP_BF16_DMA=0 keeps the register-staged kernel for every shape.  Both deal k to the MFMA slots alike and add in the
+    same order: the SAME bits -- probabilities, gradients, and weights after steps with the fused update.  The three nets
+    between them take every instance the launcher picks: 32 x 64 and 64 x 64 tiles with two images (short K; the gradient +
+    update products), 64 x 64 with three (K >= 2048: BASELINE configs[3]'s own products), 128 x 128 with three (2 048 rows).
+    The middle-sized net is also held against the bf16-aware fp64 oracle, every element of every gradient."""
+    import os
+    if os.environ.get("GNN_MLP_PATH"):
+        pytest.skip("path forced by the environment")
+    rng = np.random.default_rng(9)
+    X = rng.random((B, dims[0])) * (rng.random((B, dims[0])) < 0.2)
+    Y = np.eye(dims[-1])[rng.integers(0, dims[-1], B)]
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn.DTYPE_BF16, max_batch=B)
+    monkeypatch.setenv("GNN_MLP_BF16_DMA", "0")
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn.DTYPE_BF16, max_batch=B)
+    monkeypatch.delenv("GNN_MLP_BF16_DMA")
+    w = a.get_weights() * 0.1
+    a.set_weights(w); b.set_weights(w)
+    assert np.array_equal(a.propagate(X), b.propagate(X))
+    ga, gb = a.calculateWeightGradient(X, Y), b.calculateWeightGradient(X, Y)
+    for l in ga:
+        assert np.array_equal(ga[l], gb[l]), "layer %d" % l
+    if dims[0] == 512:
+        Ws = np_oracle.split(a.get_weights(), dims)
+        gq = np_oracle.gradient_bf16(Ws, X.astype(np.float32).astype(np.float64), Y, LEAKY)
+        off = 0
+        for l in range(len(dims) - 1):
+            n = dims[l] * dims[l + 1]
+            ref_l = gq[off:off + n].reshape(dims[l], dims[l + 1]); off += n
+            assert np.abs(ga[l] - ref_l).max() <= 4e-3 * np.abs(ref_l).max() + 1e-7, "layer %d" % l
+    for s in range(2):
+        a.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+        b.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    assert np.array_equal(a.get_momentum(), b.get_momentum())

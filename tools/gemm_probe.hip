@@ -4,7 +4,9 @@
 #define GNN_GEMM_BF16_STAMPS
 #include "../graph-neural-net_amd/csrc/gemm_wavek.h"
 #include "../graph-neural-net_amd/csrc/gemm_bf16.h"
+#include "../graph-neural-net_amd/csrc/gemm_bf16_dma.h"
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
@@ -116,6 +118,56 @@ void runb(const char *what, int M, int N, int K) {
                (st[1] + st[5]) / steps, (st[2] + st[6]) / steps, (st[3] + st[7]) / steps, (st[4] + st[8]) / steps, st[0] / steps, st[9] / steps);
     }
     printf("%-34s %4dx%4dx%4d  bf16 tile %3dx%-3d stages %d waves %d  %8.2f us  %6.1f TFLOP/s (%4.1f %% of 2500)  %d tiles\n", what, M, N, K, BM, BN, NSTG, WM * 2, us, tf, 100.0 * tf / 2500.0,
+           (int)(grid.x * grid.y));
+    fflush(stdout);
+}
+
+// the DMA form (gemm_bf16_dma.h): timing, and -- EPI_STORE / EPI_ACT -- its result against gemm_bf16_kernel's on the same operands
+template <int BM, int BN, bool AK, bool BKC, int EPI, int NIMG = 3, int WM = 2>
+void rund(const char *what, int M, int N, int K, bool check = false) {
+    GemmBf16Params p{};
+    p.A = reinterpret_cast<const __bf16 *>(dA); p.lda = (AK ? K : M) + g_pad;
+    p.B = reinterpret_cast<const __bf16 *>(dB); p.ldb = (BKC ? K : N) + g_pad;
+    p.C = dC; p.ldc = N + g_pad; p.Cb = reinterpret_cast<__bf16 *>(dAux);
+    p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
+    p.aux = dW; p.ldaux = N + g_pad; p.W = dW; p.V = dV; p.Wb = reinterpret_cast<__bf16 *>(dAux); p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
+    if (EPI == EPI_SGD) { p.C = nullptr; p.Cb = nullptr; }
+    constexpr size_t lds = gemm_bf16_dma_lds_bytes<BM, BN, NIMG>();
+    auto kern = gemm_bf16_dma_kernel<BM, BN, AK, BKC, EPI, WM, NIMG>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (M % BM || N % BN || K % GemmBf16Depth<BM>::BK) { printf("%s: shape does not fit the DMA form\n", what); return; }
+    dim3 grid(N / BN, M / BM), block(WM * 128);
+    if (check && EPI != EPI_SGD) {
+        std::vector<float> c0((size_t)M * p.ldc), c1((size_t)M * p.ldc);
+        CK(hipMemset(dC, 0, (size_t)M * p.ldc * 4));
+        hipLaunchKernelGGL(kern, grid, block, lds, 0, GNN_GEMM_HEAD_ARGS(p), p);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(c1.data(), dC, c1.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(dC, 0, (size_t)M * p.ldc * 4));
+        constexpr size_t lds0 = gemm_bf16_lds_bytes<BM, BN, AK, BKC, 2>();
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, AK, BKC, EPI, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, EPI, 2, 2>), grid, dim3(256), lds0, 0, GNN_GEMM_HEAD_ARGS(p), p);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(c0.data(), dC, c0.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0, big = 0; size_t bad = 0;
+        for (int m = 0; m < M; m++)
+            for (int n = 0; n < N; n++) {
+                const double a = c0[(size_t)m * p.ldc + n], b = c1[(size_t)m * p.ldc + n];
+                if (!(std::fabs(a - b) <= 1e-4 * std::max(1.0, std::fabs(a)))) bad++;
+                worst = std::max(worst, std::fabs(a - b)); big = std::max(big, std::fabs(a));
+            }
+        printf("    check against gemm_bf16_kernel: max |diff| %.3g (max |value| %.3g), %zu of %zu elements differ by more than 1e-4\n", worst, big, bad, (size_t)M * N);
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, grid, block, lds, 0, GNN_GEMM_HEAD_ARGS(p), p);
+    CK(hipDeviceSynchronize());
+    const int iters = 30;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kern, grid, block, lds, 0, GNN_GEMM_HEAD_ARGS(p), p);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    printf("%-34s %4dx%4dx%4d  bf16 DMA  %3dx%-3d images %d waves %d  %8.2f us  %6.1f TFLOP/s (%4.1f %% of 2500)  %d tiles\n", what, M, N, K, BM, BN, NIMG, WM * 2, us, tf, 100.0 * tf / 2500.0,
            (int)(grid.x * grid.y));
     fflush(stdout);
 }
@@ -285,6 +337,59 @@ int main(int argc, char **argv) {
         ABLS("forward 1", 64, 64, true, false, EPI_ACT, 2, 512, 2048, 4096)
         ABLS("forward 1", 64, 64, true, false, EPI_ACT, 4, 512, 2048, 4096)
         ABLS("backward data 1", 64, 64, true, true, EPI_DACT, 2, 512, 2048, 2048)
+        return 0;
+    }
+    if (which == 37) {
+        printf("---- round 4: operand tiles by LDS DMA (gemm_bf16_dma.h) against the register-staged kernel (stages 5, eight waves: what ships)\n");
+        { // operands that are numbers in BOTH halves of every float
+            const size_t nb = ((size_t)4096 * (2048 + 256) + 4096) * 2;
+            std::vector<unsigned short> hb(nb);
+            for (size_t i = 0; i < nb; i++) { const float f = (rand() / (float)RAND_MAX - 0.5f) * 0.25f; unsigned u; memcpy(&u, &f, 4); hb[i] = (unsigned short)(u >> 16); }
+            CK(hipMemcpy(dA, hb.data(), nb * 2, hipMemcpyHostToDevice));
+            for (size_t i = 0; i < nb; i++) { const float f = (rand() / (float)RAND_MAX - 0.5f) * 0.25f; unsigned u; memcpy(&u, &f, 4); hb[i] = (unsigned short)(u >> 16); }
+            CK(hipMemcpy(dB, hb.data(), nb * 2, hipMemcpyHostToDevice));
+        }
+        rund<64, 64, true, false, EPI_STORE, 3, 2>("forward 1", 512, 2048, 4096, true);
+        rund<64, 64, true, false, EPI_STORE, 2, 4>("forward 1", 512, 2048, 4096, true);
+        rund<64, 64, true, true, EPI_STORE, 3, 4>("backward data 1", 512, 2048, 2048, true);
+        rund<64, 64, false, false, EPI_STORE, 3, 2>("gradient 1", 2048, 2048, 512, true);
+        rund<32, 64, true, false, EPI_STORE, 3, 2>("logits", 512, 1024, 2048, true);
+        rund<128, 128, true, false, EPI_STORE, 2, 2>("forward, 128 x 128", 2048, 2048, 1024, true);
+        rund<128, 128, false, false, EPI_STORE, 2, 2>("gradient, 128 x 128", 2048, 2048, 512, true);
+        rund<128, 128, true, true, EPI_STORE, 2, 2>("backward, 128 x 128", 2048, 2048, 512, true);
+        for (int rep = 0; rep < 2; rep++) {
+#define DFORMS(name, BM_, BN_, AK, BKC, EPI, M, N, K) \
+            runb<BM_, BN_, AK, BKC, EPI, 5, 4>(name, M, N, K); \
+            rund<BM_, BN_, AK, BKC, EPI, 2, 2>(name, M, N, K); rund<BM_, BN_, AK, BKC, EPI, 2, 4>(name, M, N, K); \
+            rund<BM_, BN_, AK, BKC, EPI, 3, 2>(name, M, N, K); rund<BM_, BN_, AK, BKC, EPI, 3, 4>(name, M, N, K);
+            DFORMS("forward 1", 64, 64, true, false, EPI_ACT, 512, 2048, 4096)
+            DFORMS("forward 2", 64, 64, true, false, EPI_ACT, 512, 2048, 2048)
+            DFORMS("backward data 2", 64, 64, true, true, EPI_DACT, 512, 2048, 1024)
+            DFORMS("backward data 1", 64, 64, true, true, EPI_DACT, 512, 2048, 2048)
+            DFORMS("gradient + update 0", 64, 64, false, false, EPI_SGD, 4096, 2048, 512)
+            DFORMS("gradient + update 1", 64, 64, false, false, EPI_SGD, 2048, 2048, 512)
+            DFORMS("gradient + update 2", 64, 64, false, false, EPI_SGD, 2048, 1024, 512)
+            runb<32, 64, true, false, EPI_STORE, 5, 2>("logits", 512, 1024, 2048);
+            rund<32, 64, true, false, EPI_STORE, 2, 2>("logits", 512, 1024, 2048);
+            rund<32, 64, true, false, EPI_STORE, 3, 2>("logits", 512, 1024, 2048);
+            rund<64, 64, true, false, EPI_STORE, 3, 4>("logits", 512, 1024, 2048);
+        }
+        return 0;
+    }
+    if (which == 38) {
+        printf("---- round 4: DMA form, 128 x 128 tiles: one K-slice of a split-K product per workgroup (256 workgroups)\n");
+        for (int rep = 0; rep < 2; rep++) {
+            rund<128, 128, true, false, EPI_ACT, 2, 2>("forward 1: 64 tiles x 4 slices as", 2048, 2048, 1024);
+            rund<128, 128, true, false, EPI_ACT, 3, 2>("forward 1: 64 tiles x 4 slices as", 2048, 2048, 1024);
+            rund<128, 128, true, false, EPI_ACT, 2, 4>("forward 1: 64 tiles x 4 slices as", 2048, 2048, 1024);
+            rund<128, 128, true, false, EPI_ACT, 3, 4>("forward 1: 64 tiles x 4 slices as", 2048, 2048, 1024);
+            rund<128, 128, true, false, EPI_ACT, 3, 4>("forward 2: 64 tiles x 4 slices as", 2048, 2048, 512);
+            rund<128, 128, true, true, EPI_DACT, 3, 4>("backward data 1: 64 x 4 as", 2048, 2048, 512);
+            rund<128, 128, true, true, EPI_DACT, 3, 2>("backward data 1: 64 x 4 as", 2048, 2048, 512);
+            rund<128, 128, true, false, EPI_ACT, 3, 4>("(big square)", 4096, 2048, 2048);
+            rund<64, 64, true, false, EPI_ACT, 3, 4>("(big square)", 4096, 2048, 2048);
+            runb<128, 128, true, false, EPI_ACT, 2, 2>("(big square)", 4096, 2048, 2048);
+        }
         return 0;
     }
     if (which == 31) {
