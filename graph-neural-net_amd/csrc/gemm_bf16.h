@@ -14,13 +14,15 @@
 //   forward   Z  = A . W        A [B][d_in] k-contiguous,   W [d_in][d_out] k-major
 //   backward  D' = D . W^T      D [B][d_out] k-contiguous,  W as stored is k-contiguous for this product
 //   gradient  G  = A^T . D      both operands k-major ([B][d] with k = batch row)
-// A k-contiguous tile is staged as [row][k] (row stride 72 bf16 = 144 B = 36 banks: ds_read_b64 of 16 rows x
-// 2 k-groups is conflict-free); a k-major tile is staged AS IT IS, [k][n] with a row stride of 32*odd bytes,
-// and read with ds_read_b64_tr_b16, the gfx950 transpose read (per 16 lanes: a 4 x 16 block, lane i gets
-// column i).  So that those reads are conflict-free the k values of one MFMA are dealt to the four 16-lane
-// groups as  element j < 4: k = 4g + j,  j >= 4: k = 16 + 4g + (j - 4)  -- any assignment of distinct k
-// to slots is a valid product as long as both operands use the same one; a 32-lane half then reads rows
-// 0..7 (16..23) of the block, eight rows x 32 B = all 64 banks once.
+// A k-contiguous tile is staged as [row][k] (row stride BK + 16 bf16 = 8 banks mod 16) and a fragment is ONE ds_read_b128
+// (lane (fr, fg): k = kk + 8 fg .. + 7 of row fr; see LDK in the kernel for why not two ds_read_b64); a k-major tile is staged
+// AS IT IS, [k][n] with a row stride of 32*odd bytes, and read with ds_read_b64_tr_b16, the gfx950 transpose read (per 16
+// lanes: a 4 x 16 block, lane i gets column i).  So that those reads are conflict-free the k values of one MFMA are dealt to
+// the four 16-lane groups as  element j < 4: k = 4g + j,  j >= 4: k = 16 + 4g + (j - 4)  -- any assignment of distinct k to
+// slots is a valid product as long as both operands use the same one; a 32-lane half then reads rows 0..7 (16..23) of the
+// block, eight rows x 32 B = all 64 banks once.  A product with one operand of each kind (forward) writes the k-major image
+// with its rows permuted so that the same reads deliver k = 8g + j, the k-contiguous operand's assignment.
+// gemm_bf16_dma.h holds the form that brings whole tiles into LDS by DMA; this kernel takes every shape.
 #pragma once
 #include "kernels.h"
 

@@ -87,7 +87,13 @@ void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
         else if (t64 <= 1024) launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI, 4, 5>(h, cls, p);
         else launch_gemm_bf16_t<64, 64, A_KC, B_KC, EPI>(h, cls, p);
         break;
-    default: launch_gemm_bf16_t<32, 32, A_KC, B_KC, EPI>(h, cls, p); break;
+    default:
+        // 256 x 1024 x 1024 (configs[4]): 6.2 -> 5.0 us forward, 5.4 -> 5.0 backward data by DMA (profiles/r04/gemm_probe_bf16_configs4.log);
+        // ragged K (784) keeps the register-staged kernel, two images there for the forward form (6.4 -> 6.1)
+        if (launch_gemm_bf16_dma_t<32, 32, A_KC, B_KC, EPI, 2, 2>(h, cls, p)) break;
+        if constexpr (A_KC && !B_KC) launch_gemm_bf16_t<32, 32, A_KC, B_KC, EPI, 2, 5>(h, cls, p);
+        else launch_gemm_bf16_t<32, 32, A_KC, B_KC, EPI>(h, cls, p);
+        break;
     }
 }
 

@@ -157,12 +157,12 @@ def test_bf16_rowblock_kernel_against_middle4(gnn, monkeypatch, dims, B, inner):
     assert np.mean(np.abs(new.get_weights() - w)) <= 2e-5
 
 
-@pytest.mark.parametrize("dims,B", [([512, 1024, 1024, 512], 512), ([4096, 2048, 2048, 1024], 512), ([256, 2048, 2048, 16], 2048)])
+@pytest.mark.parametrize("dims,B", [([512, 1024, 1024, 512], 512), ([4096, 2048, 2048, 1024], 512), ([256, 2048, 2048, 16], 2048), ([1024, 1024, 1024, 16], 256)])
 def test_bf16_dma_form_equals_register_staged(gnn, monkeypatch, dims, B):
     """Whole-tile products take gemm_bf16_dma_kernel (operand tiles by LDS DMA into permuted images, gemm_bf16_dma.h);
     GNN_MLP_BF16_DMA=0 keeps the register-staged kernel for every shape.  Both deal k to the MFMA slots alike and add in the
     same order: the SAME bits -- probabilities, gradients, and weights after steps with the fused update.  The three nets
-    between them take every instance the launcher picks: 32 x 64 and 64 x 64 tiles with two images (short K; the gradient +
+    between them take every instance the launcher picks: 32 x 32 (256 rows), 32 x 64 and 64 x 64 tiles with two images (short K; the gradient +
     update products), 64 x 64 with three (K >= 2048: BASELINE configs[3]'s own products), 128 x 128 with three (2 048 rows).
     The middle-sized net is also held against the bf16-aware fp64 oracle, every element of every gradient."""
     import os

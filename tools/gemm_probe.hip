@@ -392,6 +392,27 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (which == 40) {
+        printf("---- round 4: configs[4]'s bf16 products (256 rows): the shipped 32 x 32 register-staged tiles against two images and the DMA form\n");
+        for (int rep = 0; rep < 2; rep++) {
+            runb<32, 32, true, false, EPI_ACT, 2, 2>("forward 2/3 (shipped)", 256, 1024, 1024);
+            runb<32, 32, true, false, EPI_ACT, 5, 2>("forward 2/3", 256, 1024, 1024);
+            rund<32, 32, true, false, EPI_ACT, 2, 2>("forward 2/3", 256, 1024, 1024);
+            rund<32, 32, true, false, EPI_ACT, 3, 2>("forward 2/3", 256, 1024, 1024);
+            rund<32, 64, true, false, EPI_ACT, 2, 2>("forward 2/3", 256, 1024, 1024);
+            rund<64, 64, true, false, EPI_ACT, 2, 4>("forward 2/3", 256, 1024, 1024);
+            runb<32, 32, true, true, EPI_DACT, 2, 2>("backward data (shipped)", 256, 1024, 1024);
+            runb<32, 32, true, true, EPI_DACT, 5, 2>("backward data", 256, 1024, 1024);
+            rund<32, 32, true, true, EPI_DACT, 2, 2>("backward data", 256, 1024, 1024);
+            rund<32, 32, true, true, EPI_DACT, 3, 2>("backward data", 256, 1024, 1024);
+            rund<64, 64, true, true, EPI_DACT, 2, 4>("backward data", 256, 1024, 1024);
+            runb<32, 32, true, false, EPI_ACT, 2, 2>("forward 1 (shipped; K = 784)", 256, 1024, 784);
+            runb<32, 32, true, false, EPI_ACT, 5, 2>("forward 1 (K = 784)", 256, 1024, 784);
+            runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 0 (M = 784)", 784, 1024, 256);
+            runb<64, 64, false, false, EPI_SGD, 5, 4>("gradient + update 0 (M = 784)", 784, 1024, 256);
+        }
+        return 0;
+    }
     if (which == 31) {
         printf("---- round 4: the bf16 gradient + update products (each three times)\n");
         for (int rep = 0; rep < 3; rep++) {
