@@ -147,6 +147,7 @@ struct gnn_mlp {
     int env_path = 0;          // GNN_MLP_PATH: 0 default, 1 "generic", 2 "nomid4"
     int env_hybrid = -1;       // GNN_MLP_HYBRID: -1 unset, else bit 0 = fwd_first, bit 1 = grad_update
     bool env_tail_off = false; // GNN_MLP_TAIL=0: the three-launch form instead of tail_kernel
+    bool env_f32_dma_off = false;  // GNN_MLP_F32_DMA=0: gemm_f32_kernel for every shape (development)
     bool env_bf16_dma_off = false; // GNN_MLP_BF16_DMA=0: the register-staged bf16 GEMM for every shape (development)
     bool env_wavek_off = false; // GNN_MLP_WAVEK=0: gemm_f32_kernel<32, 32> instead of the wave-K kernel (development)
     bool env_graph = false;    // GNN_MLP_GRAPH=1: train_range replays a captured pass

@@ -99,6 +99,68 @@ struct GemmParams {
     int act;
 };
 
+// ---- epilogue of the f32 GEMM kernels (gemm_f32_kernel, gemm_f32_dma_kernel) -------------------------------------
+// C/D map of the 16x16 MFMA: tile column gamma = lane & 15, tile row rho = (lane >> 4) * 4 + reg; the kernels interleave
+// their fragments so that MFMA tile (i, j) of a wave holds rows base + TM * rho + i and columns base + TN * gamma + j:
+// a lane stores TN consecutive columns.
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void gemm_f32_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0, int wm, int wn, int fr, int fq) {
+    typedef float vec_b __attribute__((ext_vector_type(TN == 1 ? 2 : TN)));
+    const int n = n0 + wn * (TN * 16) + fr * TN; // this lane's TN consecutive columns (all inside or all outside N)
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = m0 + wm * (TM * 16) + (fq * 4 + r) * TM + i;
+            if (m < p.M && n < p.N) {
+                const size_t off = (size_t)m * p.ldc + n;
+                float v[TN], aux[TN], vold[TN], wold[TN];
+                if (EPI == EPI_DACT) {
+                    if constexpr (TN == 1) aux[0] = p.aux[(size_t)m * p.ldaux + n];
+                    else {
+                        const vec_b t_ = *reinterpret_cast<const vec_b *>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+                        for (int j = 0; j < TN; j++) aux[j] = t_[j];
+                    }
+                }
+                if (EPI == EPI_SGD) {
+                    if constexpr (TN == 1) { vold[0] = p.V[off]; wold[0] = p.W[off]; }
+                    else {
+                        const vec_b tv = *reinterpret_cast<const vec_b *>(p.V + off), tw = *reinterpret_cast<const vec_b *>(p.W + off);
+#pragma unroll
+                        for (int j = 0; j < TN; j++) { vold[j] = tv[j]; wold[j] = tw[j]; }
+                    }
+                }
+                float out0[TN], out1[TN]; // out0: C (or W), out1: V
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const bool live = (m < p.m_true) && (n + j < p.n_true);
+                    v[j] = acc[i][j][r];
+                    if (EPI == EPI_STORE) out0[j] = live ? v[j] : 0.f;
+                    else if (EPI == EPI_ACT) out0[j] = live ? act_fn(p.act, v[j]) : 0.f;
+                    else if (EPI == EPI_DACT) out0[j] = live ? v[j] * act_prime_from_a(p.act, aux[j]) : 0.f;
+                    else { // EPI_SGD: ((step*G)/B) + (momentum*prev), SCE:333; padding elements stay as they are (zeros)
+                        const float adj = sgd_adj(p.step_over_b, v[j], p.momentum, vold[j]);
+                        out0[j] = live ? wold[j] - adj : wold[j];
+                        out1[j] = live ? adj : vold[j];
+                    }
+                }
+                float *dst0 = (EPI == EPI_SGD) ? p.W + off : p.C + off;
+                if constexpr (TN == 1) {
+                    dst0[0] = out0[0];
+                    if (EPI == EPI_SGD) p.V[off] = out1[0];
+                } else {
+                    vec_b o0, o1;
+#pragma unroll
+                    for (int j = 0; j < TN; j++) { o0[j] = out0[j]; if (EPI == EPI_SGD) o1[j] = out1[j]; }
+                    *reinterpret_cast<vec_b *>(dst0) = o0;
+                    if (EPI == EPI_SGD) *reinterpret_cast<vec_b *>(p.V + off) = o1;
+                }
+            }
+        }
+    }
+}
+
 // WM: wave rows (waves are WM x 2, WM * 128 threads).  WM = 4 puts EIGHT waves on a tile -- two per SIMD from one
 // workgroup, which is what covers barriers and LDS latency when the grid has only one workgroup per CU.
 // NSTG: k tiles held in registers ahead of the one being multiplied (see the main loop).  ONE for every tile: with two, the
@@ -189,6 +251,10 @@ __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GNN_GEMM_HEAD_PARAMS
         }
     };
     auto store_tiles = [&](const float4 (&ra)[NA], const float4 (&rb)[NB]) {
+#ifdef GNN_F32_NO_LDS_WRITES // (tools/gemm_probe, timing only: what the write phase of the loop costs)
+        asm volatile("" ::"v"(ra[0].x), "v"(rb[0].x));
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int idx = t + i * NT;
@@ -320,61 +386,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_f32_kernel(GNN_GEMM_HEAD_PARAMS
     if (interior) main_loop(BoolC<true>{});
     else main_loop(BoolC<false>{});
 
-    // epilogue: C/D map of the 16x16 MFMA: tile column gamma = lane&15, tile row rho = (lane>>4)*4 + reg;
-    // with the interleaving above, row = base + TM*rho + i and columns base + TN*gamma + (0..TN-1)
-    const int n = n0 + wn * (TN * 16) + fr * TN; // this lane's TN consecutive columns (all inside or all outside N)
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int m = m0 + wm * (TM * 16) + (fq * 4 + r) * TM + i;
-            if (m < p.M && n < p.N) {
-                const size_t off = (size_t)m * p.ldc + n;
-                float v[TN], aux[TN], vold[TN], wold[TN];
-                if (EPI == EPI_DACT) {
-                    if constexpr (TN == 1) aux[0] = p.aux[(size_t)m * p.ldaux + n];
-                    else {
-                        const vec_b t_ = *reinterpret_cast<const vec_b *>(p.aux + (size_t)m * p.ldaux + n);
-#pragma unroll
-                        for (int j = 0; j < TN; j++) aux[j] = t_[j];
-                    }
-                }
-                if (EPI == EPI_SGD) {
-                    if constexpr (TN == 1) { vold[0] = p.V[off]; wold[0] = p.W[off]; }
-                    else {
-                        const vec_b tv = *reinterpret_cast<const vec_b *>(p.V + off), tw = *reinterpret_cast<const vec_b *>(p.W + off);
-#pragma unroll
-                        for (int j = 0; j < TN; j++) { vold[j] = tv[j]; wold[j] = tw[j]; }
-                    }
-                }
-                float out0[TN], out1[TN]; // out0: C (or W), out1: V
-#pragma unroll
-                for (int j = 0; j < TN; j++) {
-                    const bool live = (m < p.m_true) && (n + j < p.n_true);
-                    v[j] = acc[i][j][r];
-                    if (EPI == EPI_STORE) out0[j] = live ? v[j] : 0.f;
-                    else if (EPI == EPI_ACT) out0[j] = live ? act_fn(p.act, v[j]) : 0.f;
-                    else if (EPI == EPI_DACT) out0[j] = live ? v[j] * act_prime_from_a(p.act, aux[j]) : 0.f;
-                    else { // EPI_SGD: ((step*G)/B) + (momentum*prev), SCE:333; padding elements stay as they are (zeros)
-                        const float adj = sgd_adj(p.step_over_b, v[j], p.momentum, vold[j]);
-                        out0[j] = live ? wold[j] - adj : wold[j];
-                        out1[j] = live ? adj : vold[j];
-                    }
-                }
-                float *dst0 = (EPI == EPI_SGD) ? p.W + off : p.C + off;
-                if constexpr (TN == 1) {
-                    dst0[0] = out0[0];
-                    if (EPI == EPI_SGD) p.V[off] = out1[0];
-                } else {
-                    vec_b o0, o1;
-#pragma unroll
-                    for (int j = 0; j < TN; j++) { o0[j] = out0[j]; if (EPI == EPI_SGD) o1[j] = out1[j]; }
-                    *reinterpret_cast<vec_b *>(dst0) = o0;
-                    if (EPI == EPI_SGD) *reinterpret_cast<vec_b *>(p.V + off) = o1;
-                }
-            }
-        }
-    }
+    gemm_f32_epilogue<TM, TN, EPI>(acc, p, m0, n0, wm, wn, fr, fq);
 }
 
 // ------------------------------------------------------------------------------------------

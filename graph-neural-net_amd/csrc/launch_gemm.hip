@@ -1,6 +1,7 @@
 // launch_gemm.hip -- host side of the per-layer f32 GEMM path (kernels.h, gemm_wavek.h) and of the three-launch
 // small-net kernels (fused_kernels.h): tile choice and launches.
 #include "handle.h"
+#include "gemm_f32_dma.h"
 
 using namespace gnn;
 using namespace gnn::host;
@@ -13,6 +14,26 @@ template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2>
 void launch_gemm_t(gnn_mlp *h, int cls, const GemmParams &p) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
     launch_timed(h, cls, gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, WM>, grid, dim3(WM * 128), 0, GNN_GEMM_HEAD_ARGS(p), p);
+}
+
+// Operand tiles by LDS DMA (gemm_f32_dma.h): whole 64 x 64 tiles of the forms with a k-contiguous operand, whose transposing
+// ds_write_b32 stores it removes -- backward data 512 x 2048 x 2048 47.0 -> 39.4 us, 512 x 2048 x 1024 23.7 -> 21.0, forward
+// 512 x 2048 x 4096 78.7 -> 76.6 (profiles/r04/gemm_probe_f32_dma.log).  The gradient forms (both operands k-major, already
+// written with ds_write_b128) gain nothing from it and stay on gemm_f32_kernel.
+template <bool A_KC, bool B_KC, int EPI>
+bool launch_gemm_dma64(gnn_mlp *h, int cls, const GemmParams &p) {
+    if (h->env_f32_dma_off || p.M % 64 || p.N % 64 || p.K % GemmF32DmaDepth<64>::BK) return false;
+    constexpr size_t lds = gemm_f32_dma_lds_bytes<64, 64, 3>();
+    auto kern = gemm_f32_dma_kernel<64, 64, A_KC, B_KC, EPI, 4, 3>;
+    static bool opted_in = false; // more than 64 KB of dynamic LDS needs the opt-in, once per instantiation
+    if (!opted_in) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            if (h->launch_error == hipSuccess) h->launch_error = hipGetLastError();
+        }
+        opted_in = true;
+    }
+    launch_timed(h, cls, kern, dim3(p.N / 64, p.M / 64), dim3(512), lds, GNN_GEMM_HEAD_ARGS(p), p);
+    return true;
 }
 
 // tile edge: keep >= ~256 workgroups in flight where the problem allows it (256 CUs)
@@ -54,6 +75,9 @@ void launch_gemm(gnn_mlp *h, int cls, const GemmParams &p) {
     //   gradient (both k-major): 64 x 32 below 512 tiles of 64 x 64; 128 x 128 tiles only from 512 of them up, 256..511 of them
     //     run as 64 x 64 (2048 x 2048 x 512 with the update: 45.4 against 48.1 us).
     const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64), t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if constexpr (A_KC) {
+        if (tile == 64 && launch_gemm_dma64<A_KC, B_KC, EPI>(h, cls, p)) return;
+    }
     if (tile == 64 && t64 < 512) {
         if constexpr (A_KC) launch_gemm_t<64, 64, A_KC, B_KC, EPI, 4>(h, cls, p);
         else launch_gemm_t<64, 32, A_KC, B_KC, EPI>(h, cls, p);

@@ -999,3 +999,41 @@ def test_ragged_wave_k_first_layer(gnn, monkeypatch, dims, B, inner):
     hits = net.count_hits_range(0, B)
     want = int((np.argmax(Z[-1], axis=1) == np.argmax(Y, axis=1)).sum())
     assert abs(hits - want) <= int((~clear).sum())
+
+
+def test_f32_dma_form_against_register_staged_and_oracle(gnn, monkeypatch):
+    """Whole 64 x 64 tiles of the forward and backward-data products take gemm_f32_dma_kernel (operand tiles by LDS DMA,
+    gemm_f32_dma.h; GNN_MLP_F32_DMA=0 keeps gemm_f32_kernel).  It adds the same f32 products in another order (an MFMA sums
+    k = kk + j, kk + 4 + j, ... where the register-staged kernel's sums kk .. kk + 3), so the two are compared to rounding, and
+    both against the fp64 matrix form.  512 rows of 1024-2048-2048-64: products of 16 and 32 tiles of K, and one of a single
+    tile (the backward product through the 64-wide last layer)."""
+    from tests import np_oracle
+    if os.environ.get("GNN_MLP_PATH"):
+        pytest.skip("path forced by the environment")
+    dims, B = [1024, 2048, 2048, 64], 512
+    X, Y = make_batch(dims, B, seed=55, sparse=True)
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=TANH, max_batch=B)
+    monkeypatch.setenv("GNN_MLP_F32_DMA", "0")
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, inner_act=TANH, max_batch=B)
+    monkeypatch.delenv("GNN_MLP_F32_DMA")
+    w = a.get_weights() * 0.05
+    a.set_weights(w); b.set_weights(w)
+    Ws = np_oracle.split(a.get_weights(), dims)
+    _, pr = np_oracle.forward(Ws, X, TANH)
+    pa, pb = a.propagate(X), b.propagate(X)
+    assert np.abs(pa - pr).max() <= P_ATOL and np.abs(pb - pr).max() <= P_ATOL
+    assert np.abs(pa - pb).max() <= 1e-5
+    gr = np_oracle.gradient(Ws, X, Y, TANH)
+    ga, gb = a.calculateWeightGradient(X, Y), b.calculateWeightGradient(X, Y)
+    off = 0
+    for l in range(len(dims) - 1):
+        n = dims[l] * dims[l + 1]
+        grl = gr[off:off + n].reshape(dims[l], dims[l + 1]); off += n
+        scale = np.abs(grl).max()
+        assert np.abs(ga[l] - grl).max() <= 3e-5 * scale + 1e-9, "layer %d" % l
+        assert np.abs(gb[l] - grl).max() <= 3e-5 * scale + 1e-9, "layer %d" % l
+        assert np.abs(ga[l] - gb[l]).max() <= 1e-5 * scale + 1e-9, "layer %d" % l
+    for s in range(2):
+        a.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+        b.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+    assert np.abs(a.get_weights() - b.get_weights()).max() <= W_ATOL

@@ -5,6 +5,7 @@
 #include "../graph-neural-net_amd/csrc/gemm_wavek.h"
 #include "../graph-neural-net_amd/csrc/gemm_bf16.h"
 #include "../graph-neural-net_amd/csrc/gemm_bf16_dma.h"
+#include "../graph-neural-net_amd/csrc/gemm_f32_dma.h"
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -169,6 +170,52 @@ void rund(const char *what, int M, int N, int K, bool check = false) {
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
     printf("%-34s %4dx%4dx%4d  bf16 DMA  %3dx%-3d images %d waves %d  %8.2f us  %6.1f TFLOP/s (%4.1f %% of 2500)  %d tiles\n", what, M, N, K, BM, BN, NIMG, WM * 2, us, tf, 100.0 * tf / 2500.0,
            (int)(grid.x * grid.y));
+    fflush(stdout);
+}
+
+// the f32 DMA form (gemm_f32_dma.h): timing, and its result against gemm_f32_kernel's on the same operands
+template <int BM, int BN, bool AK, bool BKC, int EPI, int NIMG = 3, int WM = 4>
+void runfd(const char *what, int M, int N, int K, bool check = false) {
+    GemmParams p{};
+    p.A = dA; p.lda = (AK ? K : M) + g_pad;
+    p.B = dB; p.ldb = (BKC ? K : N) + g_pad;
+    p.C = dC; p.ldc = N + g_pad;
+    p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
+    p.aux = dAux; p.ldaux = N + g_pad; p.W = dW; p.V = dV; p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
+    constexpr size_t lds = gemm_f32_dma_lds_bytes<BM, BN, NIMG>();
+    auto kern = gemm_f32_dma_kernel<BM, BN, AK, BKC, EPI, WM, NIMG>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (M % BM || N % BN || K % GemmF32DmaDepth<BM>::BK) { printf("%s: shape does not fit the DMA form\n", what); return; }
+    dim3 grid(N / BN, M / BM), block(WM * 128);
+    if (check && EPI != EPI_SGD) {
+        std::vector<float> c0((size_t)M * p.ldc), c1((size_t)M * p.ldc);
+        CK(hipMemset(dC, 0, (size_t)M * p.ldc * 4));
+        hipLaunchKernelGGL(kern, grid, block, lds, 0, GNN_GEMM_HEAD_ARGS(p), p);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(c1.data(), dC, c1.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(dC, 0, (size_t)M * p.ldc * 4));
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BKC, EPI, WM>), grid, block, 0, 0, GNN_GEMM_HEAD_ARGS(p), p);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(c0.data(), dC, c0.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0, big = 0; size_t bad = 0;
+        for (int m = 0; m < M; m++)
+            for (int n = 0; n < N; n++) {
+                const double a = c0[(size_t)m * p.ldc + n], b = c1[(size_t)m * p.ldc + n];
+                if (!(std::fabs(a - b) <= 2e-5 * std::max(0.05, std::fabs(a)))) bad++;
+                worst = std::max(worst, std::fabs(a - b)); big = std::max(big, std::fabs(a));
+            }
+        printf("    check against gemm_f32_kernel: max |diff| %.3g (max |value| %.3g), %zu of %zu elements differ by more than 2e-5 relative\n", worst, big, bad, (size_t)M * N);
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, grid, block, lds, 0, GNN_GEMM_HEAD_ARGS(p), p);
+    CK(hipDeviceSynchronize());
+    const int iters = 30;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kern, grid, block, lds, 0, GNN_GEMM_HEAD_ARGS(p), p);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    printf("%-34s %4dx%4dx%4d  f32 DMA %3dx%-3d images %d waves %d  %8.2f us  %6.1f TFLOP/s (%4.1f %%)  %d tiles\n", what, M, N, K, BM, BN, NIMG, WM * 2, us, tf, 100.0 * tf / 157.3, (int)(grid.x * grid.y));
     fflush(stdout);
 }
 
@@ -410,6 +457,55 @@ int main(int argc, char **argv) {
             runb<32, 32, true, false, EPI_ACT, 5, 2>("forward 1 (K = 784)", 256, 1024, 784);
             runb<64, 64, false, false, EPI_SGD, 2, 2>("gradient + update 0 (M = 784)", 784, 1024, 256);
             runb<64, 64, false, false, EPI_SGD, 5, 4>("gradient + update 0 (M = 784)", 784, 1024, 256);
+        }
+        return 0;
+    }
+    if (which == 41) {
+#ifdef GNN_F32_NO_LDS_WRITES
+        printf("---- f32 GEMMs of configs[3] WITHOUT the LDS writes of the main loop (wrong results: an upper bound on what staging by DMA could give)\n");
+#else
+        printf("---- f32 GEMMs of configs[3] as shipped\n");
+#endif
+        for (int rep = 0; rep < 2; rep++) {
+            run<64, 64, true, false, EPI_ACT, 4, 1>("forward 1", 512, 2048, 4096);
+            run<64, 64, true, false, EPI_ACT, 4, 1>("forward 2", 512, 2048, 2048);
+            run<64, 64, true, true, EPI_DACT, 4, 1>("backward data 2", 512, 2048, 1024);
+            run<64, 64, true, true, EPI_DACT, 4, 1>("backward data 1", 512, 2048, 2048);
+            run<128, 128, false, false, EPI_SGD, 2, 1>("gradient + update 0", 4096, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 4, 1>("gradient + update 1", 2048, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 4, 1>("gradient + update 2", 2048, 1024, 512);
+        }
+        return 0;
+    }
+    if (which == 42) {
+        printf("---- round 4: f32 GEMMs of configs[3], operand tiles by LDS DMA (gemm_f32_dma.h) against gemm_f32_kernel\n");
+        runfd<64, 64, true, false, EPI_STORE, 3, 4>("forward 2", 512, 2048, 2048, true);
+        runfd<64, 64, true, true, EPI_STORE, 3, 4>("backward data 2", 512, 2048, 1024, true);
+        runfd<64, 64, false, false, EPI_STORE, 2, 4>("gradient 2", 2048, 1024, 512, true);
+        runfd<128, 128, false, false, EPI_STORE, 3, 2>("gradient 0", 4096, 2048, 512, true);
+        runfd<128, 128, true, false, EPI_STORE, 3, 2>("forward, 128 x 128", 4096, 2048, 2048, true);
+        runfd<128, 128, true, true, EPI_STORE, 3, 2>("backward, 128 x 128", 4096, 2048, 2048, true);
+        for (int rep = 0; rep < 2; rep++) {
+            run<64, 64, true, false, EPI_ACT, 4, 1>("forward 1", 512, 2048, 4096);
+            runfd<64, 64, true, false, EPI_ACT, 3, 4>("forward 1", 512, 2048, 4096);
+            runfd<64, 64, true, false, EPI_ACT, 2, 4>("forward 1", 512, 2048, 4096);
+            run<64, 64, true, false, EPI_ACT, 4, 1>("forward 2", 512, 2048, 2048);
+            runfd<64, 64, true, false, EPI_ACT, 3, 4>("forward 2", 512, 2048, 2048);
+            run<64, 64, true, true, EPI_DACT, 4, 1>("backward data 2", 512, 2048, 1024);
+            runfd<64, 64, true, true, EPI_DACT, 3, 4>("backward data 2", 512, 2048, 1024);
+            runfd<64, 64, true, true, EPI_DACT, 2, 4>("backward data 2", 512, 2048, 1024);
+            run<64, 64, true, true, EPI_DACT, 4, 1>("backward data 1", 512, 2048, 2048);
+            runfd<64, 64, true, true, EPI_DACT, 3, 4>("backward data 1", 512, 2048, 2048);
+            run<128, 128, false, false, EPI_SGD, 2, 1>("gradient + update 0", 4096, 2048, 512);
+            runfd<128, 128, false, false, EPI_SGD, 3, 2>("gradient + update 0", 4096, 2048, 512);
+            runfd<128, 128, false, false, EPI_SGD, 2, 2>("gradient + update 0", 4096, 2048, 512);
+            runfd<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 0", 4096, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 4, 1>("gradient + update 1", 2048, 2048, 512);
+            runfd<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 1", 2048, 2048, 512);
+            runfd<64, 64, false, false, EPI_SGD, 3, 4>("gradient + update 1", 2048, 2048, 512);
+            run<64, 64, false, false, EPI_SGD, 4, 1>("gradient + update 2", 2048, 1024, 512);
+            runfd<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 2", 2048, 1024, 512);
+            runfd<64, 64, false, false, EPI_SGD, 3, 4>("gradient + update 2", 2048, 1024, 512);
         }
         return 0;
     }
