@@ -44,18 +44,19 @@ template <int W> __device__ __forceinline__ constexpr int km_swz(int rho) {
 // k-major image of a mixed product: the k (inside its 32-k block) that image row rho holds
 __device__ __forceinline__ constexpr int km_row_k(int rho) { return (rho & ~31) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3); }
 
-template <int BM, int BN> struct GemmBf16Dma {
-    static constexpr int BK = GemmBf16Depth<BM>::BK;
+// (BKO: a K depth other than GemmBf16Depth's, a multiple of 64 -- tools/gemm_probe)
+template <int BM, int BN, int BKO = 0> struct GemmBf16Dma {
+    static constexpr int BK = BKO ? BKO : GemmBf16Depth<BM>::BK;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, IMG_BYTES = A_BYTES + B_BYTES;
     static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "whole DMA instructions");
 };
-template <int BM, int BN, int NIMG> constexpr size_t gemm_bf16_dma_lds_bytes() { return (size_t)NIMG * GemmBf16Dma<BM, BN>::IMG_BYTES; }
+template <int BM, int BN, int NIMG, int BKO = 0> constexpr size_t gemm_bf16_dma_lds_bytes() { return (size_t)NIMG * GemmBf16Dma<BM, BN, BKO>::IMG_BYTES; }
 template <int V> struct IntC { static constexpr int value = V; };
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2, int NIMG = 3>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2, int NIMG = 3, int BKO = 0>
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_dma_kernel(GNN_GEMM_HEAD_PARAMS(__bf16), GemmBf16Params p) {
     GNN_GEMM_TAKE_HEAD(p);
-    using D = GemmBf16Dma<BM, BN>;
+    using D = GemmBf16Dma<BM, BN, BKO>;
     constexpr int BK = D::BK, NW = WM * 2, NBLK = BK / 32;
     constexpr int TM = BM / (WM * 16), TN = BN / 32; // 16x16 MFMA tiles per wave (waves are WM x 2)
     constexpr int NIA = D::A_BYTES / 1024, NI = (D::A_BYTES + D::B_BYTES) / 1024, NPW = (NI + NW - 1) / NW; // DMA instructions: A's, all, per wave
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_dma_kernel(GNN_GEMM_HEAD_P
     }
     __syncthreads(); // the epilogue stages through the images
 
-    static_assert(2 * WM * 16 * (TN * 16 + 4) * sizeof(float) <= gemm_bf16_dma_lds_bytes<BM, BN, NIMG>(), "epilogue staging fits the images");
+    static_assert(2 * WM * 16 * (TN * 16 + 4) * sizeof(float) <= gemm_bf16_dma_lds_bytes<BM, BN, NIMG, BKO>(), "epilogue staging fits the images");
     gemm_bf16_epilogue<TM, TN, EPI>(acc, p, reinterpret_cast<float *>(smem), m0, n0, wave, lane);
 }
 

@@ -124,7 +124,7 @@ void runb(const char *what, int M, int N, int K) {
 }
 
 // the DMA form (gemm_bf16_dma.h): timing, and -- EPI_STORE / EPI_ACT -- its result against gemm_bf16_kernel's on the same operands
-template <int BM, int BN, bool AK, bool BKC, int EPI, int NIMG = 3, int WM = 2>
+template <int BM, int BN, bool AK, bool BKC, int EPI, int NIMG = 3, int WM = 2, int BKO = 0>
 void rund(const char *what, int M, int N, int K, bool check = false) {
     GemmBf16Params p{};
     p.A = reinterpret_cast<const __bf16 *>(dA); p.lda = (AK ? K : M) + g_pad;
@@ -133,10 +133,10 @@ void rund(const char *what, int M, int N, int K, bool check = false) {
     p.M = M; p.N = N; p.K = K; p.m_true = M; p.n_true = N;
     p.aux = dW; p.ldaux = N + g_pad; p.W = dW; p.V = dV; p.Wb = reinterpret_cast<__bf16 *>(dAux); p.step_over_b = 1e-6f; p.momentum = 0.9f; p.act = 0;
     if (EPI == EPI_SGD) { p.C = nullptr; p.Cb = nullptr; }
-    constexpr size_t lds = gemm_bf16_dma_lds_bytes<BM, BN, NIMG>();
-    auto kern = gemm_bf16_dma_kernel<BM, BN, AK, BKC, EPI, WM, NIMG>;
+    constexpr size_t lds = gemm_bf16_dma_lds_bytes<BM, BN, NIMG, BKO>();
+    auto kern = gemm_bf16_dma_kernel<BM, BN, AK, BKC, EPI, WM, NIMG, BKO>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (M % BM || N % BN || K % GemmBf16Depth<BM>::BK) { printf("%s: shape does not fit the DMA form\n", what); return; }
+    if (M % BM || N % BN || K % GemmBf16Dma<BM, BN, BKO>::BK) { printf("%s: shape does not fit the DMA form\n", what); return; }
     dim3 grid(N / BN, M / BM), block(WM * 128);
     if (check && EPI != EPI_SGD) {
         std::vector<float> c0((size_t)M * p.ldc), c1((size_t)M * p.ldc);
@@ -168,7 +168,7 @@ void rund(const char *what, int M, int N, int K, bool check = false) {
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-    printf("%-34s %4dx%4dx%4d  bf16 DMA  %3dx%-3d images %d waves %d  %8.2f us  %6.1f TFLOP/s (%4.1f %% of 2500)  %d tiles\n", what, M, N, K, BM, BN, NIMG, WM * 2, us, tf, 100.0 * tf / 2500.0,
+    printf("%-34s %4dx%4dx%4d  bf16 DMA  %3dx%-3d BK %3d images %d waves %d  %8.2f us  %6.1f TFLOP/s (%4.1f %% of 2500)  %d tiles\n", what, M, N, K, BM, BN, GemmBf16Dma<BM, BN, BKO>::BK, NIMG, WM * 2, us, tf, 100.0 * tf / 2500.0,
            (int)(grid.x * grid.y));
     fflush(stdout);
 }
@@ -506,6 +506,35 @@ int main(int argc, char **argv) {
             run<64, 64, false, false, EPI_SGD, 4, 1>("gradient + update 2", 2048, 1024, 512);
             runfd<64, 64, false, false, EPI_SGD, 2, 4>("gradient + update 2", 2048, 1024, 512);
             runfd<64, 64, false, false, EPI_SGD, 3, 4>("gradient + update 2", 2048, 1024, 512);
+        }
+        return 0;
+    }
+    if (which == 43) {
+        printf("---- round 4: DMA form, deeper tiles of K (fewer barriers per K) on the forward and backward-data products of configs[3]\n");
+        { // operands that are numbers in BOTH halves of every float
+            const size_t nb = ((size_t)4096 * (2048 + 256) + 4096) * 2;
+            std::vector<unsigned short> hb(nb);
+            for (size_t i = 0; i < nb; i++) { const float f = (rand() / (float)RAND_MAX - 0.5f) * 0.25f; unsigned u; memcpy(&u, &f, 4); hb[i] = (unsigned short)(u >> 16); }
+            CK(hipMemcpy(dA, hb.data(), nb * 2, hipMemcpyHostToDevice));
+            CK(hipMemcpy(dB, hb.data(), nb * 2, hipMemcpyHostToDevice));
+        }
+        rund<64, 64, true, false, EPI_STORE, 2, 4, 256>("forward 1", 512, 2048, 4096, true);
+        rund<64, 64, true, true, EPI_STORE, 2, 4, 256>("backward data 1", 512, 2048, 2048, true);
+        rund<64, 64, true, false, EPI_STORE, 3, 4, 64>("forward 1", 512, 2048, 4096, true);
+        for (int rep = 0; rep < 2; rep++) {
+            rund<64, 64, true, false, EPI_ACT, 3, 4>("forward 1", 512, 2048, 4096);
+            rund<64, 64, true, false, EPI_ACT, 2, 4, 256>("forward 1", 512, 2048, 4096);
+            rund<64, 64, true, false, EPI_ACT, 3, 4, 64>("forward 1", 512, 2048, 4096);
+            rund<64, 64, true, false, EPI_ACT, 3, 2, 64>("forward 1", 512, 2048, 4096);
+            rund<64, 64, true, false, EPI_ACT, 3, 4>("forward 2", 512, 2048, 2048);
+            rund<64, 64, true, false, EPI_ACT, 2, 4, 256>("forward 2", 512, 2048, 2048);
+            rund<64, 64, true, false, EPI_ACT, 3, 4, 64>("forward 2", 512, 2048, 2048);
+            rund<64, 64, true, true, EPI_DACT, 3, 4>("backward data 1", 512, 2048, 2048);
+            rund<64, 64, true, true, EPI_DACT, 2, 4, 256>("backward data 1", 512, 2048, 2048);
+            rund<64, 64, true, true, EPI_DACT, 3, 4, 64>("backward data 1", 512, 2048, 2048);
+            rund<64, 64, true, true, EPI_DACT, 2, 4>("backward data 2", 512, 2048, 1024);
+            rund<64, 64, true, true, EPI_DACT, 2, 4, 256>("backward data 2", 512, 2048, 1024);
+            rund<64, 64, true, true, EPI_DACT, 3, 4, 64>("backward data 2", 512, 2048, 1024);
         }
         return 0;
     }
