@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_dma_kernel(GNN_GEMM_HEAD_P
     constexpr int NIA = D::A_BYTES / 1024, NI = (D::A_BYTES + D::B_BYTES) / 1024, NPW = (NI + NW - 1) / NW; // DMA instructions: A's, all, per wave
     constexpr bool PERMUTE = (A_KC != B_KC);
     constexpr int PD = NIMG - 1; // tiles in flight ahead of the one being multiplied
-    static_assert(NIMG == 2 || NIMG == 3, "two or three images");
+    static_assert(NIMG >= 2 && NIMG <= 4, "two to four images");
     static_assert(TM >= 1 && TN >= 1, "tile too small for this many waves");
     extern __shared__ __attribute__((aligned(1024))) __bf16 gemm_bf16_dma_smem[];
     __bf16 *smem = gemm_bf16_dma_smem;
@@ -168,7 +168,10 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_dma_kernel(GNN_GEMM_HEAD_P
         if (d < nt) issue(d);
     auto tile = [&](auto IMG_, int i) {
         constexpr int IMG = decltype(IMG_)::value;
-        if (NIMG == 3 && i + 1 < nt) wait_vmcnt<NPW>(); // all but the youngest tile's instructions: tile i has landed
+        // all but the instructions of the tiles issued after tile i (at most PD - 1 of them): tile i has landed
+        const int younger = nt - 1 - i;
+        if (PD >= 3 && younger >= 2) wait_vmcnt<2 * NPW>();
+        else if (PD >= 2 && younger >= 1) wait_vmcnt<NPW>();
         else wait_vmcnt<0>();
         __syncthreads(); // every wave's share of tile i is in LDS, and every wave is past its reads of tile i - 1 ...
         if (i + PD < nt) issue((IMG + PD) % NIMG); // ... whose image takes tile i + PD
@@ -177,7 +180,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_dma_kernel(GNN_GEMM_HEAD_P
     for (int i = 0; i < nt; i += NIMG) {
         tile(IntC<0>{}, i);
         if (i + 1 < nt) tile(IntC<1>{}, i + 1);
-        if (NIMG == 3 && i + 2 < nt) tile(IntC<NIMG == 3 ? 2 : 0>{}, i + 2);
+        if (NIMG >= 3 && i + 2 < nt) tile(IntC<NIMG >= 3 ? 2 : 0>{}, i + 2);
+        if (NIMG >= 4 && i + 3 < nt) tile(IntC<NIMG >= 4 ? 3 : 0>{}, i + 3);
     }
     __syncthreads(); // the epilogue stages through the images
 

@@ -538,6 +538,32 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (which == 44) {
+        printf("---- round 4: DMA form with FOUR images (three tiles in flight per workgroup)\n");
+        { const size_t nb = ((size_t)4096 * (2048 + 256) + 4096) * 2;
+            std::vector<unsigned short> hb(nb);
+            for (size_t i = 0; i < nb; i++) { const float f = (rand() / (float)RAND_MAX - 0.5f) * 0.25f; unsigned u; memcpy(&u, &f, 4); hb[i] = (unsigned short)(u >> 16); }
+            CK(hipMemcpy(dA, hb.data(), nb * 2, hipMemcpyHostToDevice));
+            CK(hipMemcpy(dB, hb.data(), nb * 2, hipMemcpyHostToDevice)); }
+        rund<64, 64, true, false, EPI_STORE, 4, 4>("forward 1", 512, 2048, 4096, true);
+        rund<64, 64, true, true, EPI_STORE, 4, 4>("backward data 2", 512, 2048, 1024, true);
+        rund<64, 64, true, false, EPI_STORE, 4, 4, 64>("forward 1", 512, 2048, 4096, true);
+        for (int rep = 0; rep < 3; rep++) {
+            rund<64, 64, true, false, EPI_ACT, 3, 4>("forward 1", 512, 2048, 4096);
+            rund<64, 64, true, false, EPI_ACT, 4, 4>("forward 1", 512, 2048, 4096);
+            rund<64, 64, true, false, EPI_ACT, 4, 4, 64>("forward 1", 512, 2048, 4096);
+            rund<64, 64, true, false, EPI_ACT, 4, 2>("forward 1", 512, 2048, 4096);
+            rund<64, 64, true, false, EPI_ACT, 3, 4>("forward 2", 512, 2048, 2048);
+            rund<64, 64, true, false, EPI_ACT, 4, 4>("forward 2", 512, 2048, 2048);
+            rund<64, 64, true, true, EPI_DACT, 3, 4>("backward data 1", 512, 2048, 2048);
+            rund<64, 64, true, true, EPI_DACT, 4, 4>("backward data 1", 512, 2048, 2048);
+            rund<64, 64, true, true, EPI_DACT, 2, 4>("backward data 2", 512, 2048, 1024);
+            rund<64, 64, true, true, EPI_DACT, 4, 4>("backward data 2", 512, 2048, 1024);
+            rund<32, 64, true, false, EPI_STORE, 2, 2>("logits", 512, 1024, 2048);
+            rund<32, 64, true, false, EPI_STORE, 3, 2>("logits", 512, 1024, 2048);
+        }
+        return 0;
+    }
     if (which == 31) {
         printf("---- round 4: the bf16 gradient + update products (each three times)\n");
         for (int rep = 0; rep < 3; rep++) {
