@@ -30,6 +30,7 @@ void read_env(gnn_mlp *h) {
     h->env_wavek_off = is("GNN_MLP_WAVEK", "0");
     h->env_bf16_dma_off = is("GNN_MLP_BF16_DMA", "0");
     h->env_f32_dma_off = is("GNN_MLP_F32_DMA", "0");
+    h->env_bf16_group_off = is("GNN_MLP_BF16_GROUP", "0");
     h->env_rb_off = is("GNN_MLP_ROWBLOCK", "0");
     h->env_defer_off = is("GNN_MLP_DEFER", "0");
     const char *fg = getenv("GNN_MLP_FIRST_GEMM_ROWS"); // development: from how many rows on the first layer runs as a tiled GEMM (0 = never)

@@ -160,9 +160,10 @@ constexpr size_t gemm_bf16_lds_bytes() {
 
 // WM: wave rows (waves are WM x 2, WM * 128 threads); WM = 4 puts eight waves on a tile (see gemm_f32_kernel)
 // (tools/gemm_probe only: NSTG_ = NSTG + 10 x ablation -- 1: no global loads inside the loop, 2: no MFMAs, 3: no LDS reads, 4: no LDS writes)
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int NSTG_ = 2, int WM = 2>
-__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAMS(__bf16), GemmBf16Params p) {
-    GNN_GEMM_TAKE_HEAD(p);
+// (the body: one BM x BN tile of product `p`, tile column bx, tile row by -- gemm_bf16_kernel's grid gives them, the grouped
+//  kernel below finds them from a flat workgroup number)
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int NSTG_, int WM>
+__device__ __forceinline__ void gemm_bf16_tile(const GemmBf16Params &p, const int bx, const int by) {
     constexpr int NSTG = NSTG_ % 10, ABL = NSTG_ / 10;
     constexpr int NT = WM * 128;
     constexpr int BK = GemmBf16Depth<BM>::BK;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAM
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     constexpr int NA = BM * BK / 8 / NT, NB = BN * BK / 8 / NT; // 16-B chunks (8 bf16) per thread per tile
     static_assert(NA >= 1 && NB >= 1 && TM >= 1, "tile too small for this many threads");
     bf16x8 ra0[NA], rb0[NB], ra1[NA], rb1[NB]; // register stages
@@ -429,6 +430,35 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAM
 
     static_assert(2 * WM * 16 * (TN * 16 + 4) * sizeof(float) <= gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC, NSTG>(), "epilogue staging fits the operand images");
     gemm_bf16_epilogue<TM, TN, EPI>(acc, p, reinterpret_cast<float *>(gemm_bf16_smem), m0, n0, wave, lane);
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int NSTG_ = 2, int WM = 2>
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GNN_GEMM_HEAD_PARAMS(__bf16), GemmBf16Params p) {
+    GNN_GEMM_TAKE_HEAD(p);
+    gemm_bf16_tile<BM, BN, A_KC, B_KC, EPI, NSTG_, WM>(p, blockIdx.x, blockIdx.y);
+}
+
+// SEVERAL products of one form in ONE launch: the gradient (+ update) products of all layers of a net whose products are each
+// a few hundred tiles (784-1024-1024-1024-10 at 256 rows: 208 + 256 + 256 + 16 tiles of 64 x 64) -- four launches of 4-8 us,
+// each mostly launch and ramp, become one.  Workgroup w takes tile w - first[q] of product q (products in the order given:
+// the host puts the largest first).
+constexpr int GNN_GEMM_GROUP_MAX = 6;
+struct GemmBf16Group {
+    GemmBf16Params p[GNN_GEMM_GROUP_MAX];
+    int first[GNN_GEMM_GROUP_MAX + 1]; // first[q] = number of tiles before product q; first[n] = all
+    int tiles_x[GNN_GEMM_GROUP_MAX];
+    int n;
+};
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int NSTG_ = 2, int WM = 2>
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_group_kernel(GemmBf16Group g) {
+    const int w = blockIdx.x;
+    GemmBf16Params p = g.p[0]; // (selected with scalar moves: an index into the argument block would put the array in scratch)
+    int first = 0, tiles_x = g.tiles_x[0];
+#pragma unroll
+    for (int i = 1; i < GNN_GEMM_GROUP_MAX; i++)
+        if (i < g.n && w >= g.first[i]) { p = g.p[i]; first = g.first[i]; tiles_x = g.tiles_x[i]; }
+    const int local = w - first;
+    gemm_bf16_tile<BM, BN, A_KC, B_KC, EPI, NSTG_, WM>(p, local % tiles_x, local / tiles_x);
 }
 
 // f32 -> bf16 (RNE) over a flat buffer: the shadow of W after set_weights / init / load, dataset rows, ...

@@ -148,6 +148,7 @@ struct gnn_mlp {
     int env_hybrid = -1;       // GNN_MLP_HYBRID: -1 unset, else bit 0 = fwd_first, bit 1 = grad_update
     bool env_tail_off = false; // GNN_MLP_TAIL=0: the three-launch form instead of tail_kernel
     bool env_f32_dma_off = false;  // GNN_MLP_F32_DMA=0: gemm_f32_kernel for every shape (development)
+    bool env_bf16_group_off = false; // GNN_MLP_BF16_GROUP=0: one launch per layer's gradient (+ update) product (development)
     bool env_bf16_dma_off = false; // GNN_MLP_BF16_DMA=0: the register-staged bf16 GEMM for every shape (development)
     bool env_wavek_off = false; // GNN_MLP_WAVEK=0: gemm_f32_kernel<32, 32> instead of the wave-K kernel (development)
     bool env_graph = false;    // GNN_MLP_GRAPH=1: train_range replays a captured pass
@@ -253,6 +254,19 @@ template <class K, class... P> void launch_timed(gnn_mlp *h, int cls, K kernel, 
         }
     }
     hipLaunchKernelGGL(kernel, grid, block, lds, h->stream, params...);
+}
+
+// More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize -- per kernel AND per device (a handle over N
+// devices, dp.hip, launches the same instantiation on each): `done` is the instantiation's own flag array, indexed by the handle's
+// device (the handle's device is current when its kernels are launched).
+constexpr int kMaxOptInDevices = 64;
+template <class K> void opt_in_dynamic_lds(gnn_mlp *h, K kernel, size_t bytes, bool (&done)[kMaxOptInDevices]) {
+    const bool tracked = h->device >= 0 && h->device < kMaxOptInDevices;
+    if (tracked && done[h->device]) return;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        if (h->launch_error == hipSuccess) h->launch_error = hipGetLastError();
+    }
+    if (tracked) done[h->device] = true;
 }
 
 // Zero-filled device allocation.  The fill is enqueued on the HANDLE's stream: that stream is

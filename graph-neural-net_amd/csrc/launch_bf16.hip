@@ -12,14 +12,8 @@ namespace host {
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int WM = 2, int NSTG = 2>
 void launch_gemm_bf16_t(gnn_mlp *h, int cls, const GemmBf16Params &p) {
     constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN, A_KC, B_KC, NSTG>();
-    static bool opted_in = false; // more than 64 KB of dynamic LDS needs the opt-in, once per instantiation
-    if (!opted_in) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, NSTG, WM>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            if (h->launch_error == hipSuccess) h->launch_error = hipGetLastError();
-        }
-        opted_in = true;
-    }
+    static bool opted_in[kMaxOptInDevices] = {}; // (per instantiation, per device)
+    opt_in_dynamic_lds(h, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, NSTG, WM>, lds, opted_in);
     launch_timed(h, cls, gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, NSTG, WM>, dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(WM * 128), lds, GNN_GEMM_HEAD_ARGS(p), p);
 }
 // the DMA form (gemm_bf16_dma.h): whole tiles only
@@ -28,13 +22,8 @@ bool launch_gemm_bf16_dma_t(gnn_mlp *h, int cls, const GemmBf16Params &p) {
     if (h->env_bf16_dma_off || p.M % BM || p.N % BN || p.K % GemmBf16Depth<BM>::BK) return false;
     constexpr size_t lds = gemm_bf16_dma_lds_bytes<BM, BN, NIMG>();
     auto kern = gemm_bf16_dma_kernel<BM, BN, A_KC, B_KC, EPI, WM, NIMG>;
-    static bool opted_in = false;
-    if (!opted_in) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            if (h->launch_error == hipSuccess) h->launch_error = hipGetLastError();
-        }
-        opted_in = true;
-    }
+    static bool opted_in[kMaxOptInDevices] = {};
+    opt_in_dynamic_lds(h, kern, lds, opted_in);
     launch_timed(h, cls, kern, dim3(p.N / BN, p.M / BM), dim3(WM * 128), lds, GNN_GEMM_HEAD_ARGS(p), p);
     return true;
 }
@@ -120,8 +109,30 @@ void forward_bf16(gnn_mlp *h, const __bf16 *a0b, int B) {
     }
 }
 
+// the gradient (+ update) products of all layers as ONE launch (gemm_bf16_group_kernel): when each is a few hundred tiles
+template <int EPI>
+void launch_gradient_group(gnn_mlp *h, GemmBf16Group &g) {
+    constexpr size_t lds = gemm_bf16_lds_bytes<64, 64, false, false, 5>();
+    auto kern = gemm_bf16_group_kernel<64, 64, false, false, EPI, 5, 4>;
+    static bool opted_in[kMaxOptInDevices] = {};
+    opt_in_dynamic_lds(h, kern, lds, opted_in);
+    launch_timed(h, GNN_K_GRAD_GEMM0, kern, dim3(g.first[g.n]), dim3(512), lds, g);
+}
+bool gradients_in_one_launch(const gnn_mlp *h) {
+    if (h->env_bf16_group_off || h->L - 1 < 2 || h->L - 1 > GNN_GEMM_GROUP_MAX) return false;
+    int64_t tiles = 0;
+    for (int l = 0; l < h->L - 1; l++) {
+        const int64_t t = (int64_t)((h->ld[l] + 63) / 64) * ((h->ld[l + 1] + 63) / 64);
+        if (t > 512) return false; // a product that fills the chip twice over gains nothing from sharing a launch, and has its own tile choice
+        tiles += t;
+    }
+    return tiles <= 2048;
+}
+
 void backward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool fused_update, float step_over_b, float momentum) {
     const int B_pad = pad_up(B);
+    const bool grouped = gradients_in_one_launch(h);
+    GemmBf16Group grp{};
     for (int l = h->L - 2; l >= 0; l--) {
         if (l >= 1) { // delta_l = (delta_{l+1} . W_l^T) * f'(z_l)   -- before W_l is touched
             GemmBf16Params p{};
@@ -144,11 +155,22 @@ void backward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool fused_update, floa
         if (fused_update) {
             g.W = h->W + h->w_off[l]; g.V = h->V + h->w_off[l]; g.Wb = h->Wb + h->w_off[l];
             g.step_over_b = step_over_b; g.momentum = momentum;
-            launch_gemm_bf16<false, false, EPI_SGD>(h, cls, g);
+            if (!grouped) launch_gemm_bf16<false, false, EPI_SGD>(h, cls, g);
         } else {
             g.C = h->G + h->w_off[l];
-            launch_gemm_bf16<false, false, EPI_STORE>(h, cls, g);
+            if (!grouped) launch_gemm_bf16<false, false, EPI_STORE>(h, cls, g);
         }
+        if (grouped) grp.p[l] = g; // (slot l: layer 0, the largest at MNIST-like shapes, first.  Every backward-data product
+                                   //  above reads its W before ANY update runs: the grouped launch comes after the loop.)
+    }
+    if (grouped) {
+        grp.n = h->L - 1;
+        for (int l = 0; l < grp.n; l++) {
+            grp.tiles_x[l] = (grp.p[l].N + 63) / 64;
+            grp.first[l + 1] = grp.first[l] + grp.tiles_x[l] * ((grp.p[l].M + 63) / 64);
+        }
+        if (fused_update) launch_gradient_group<EPI_SGD>(h, grp);
+        else launch_gradient_group<EPI_STORE>(h, grp);
     }
 }
 

@@ -25,13 +25,8 @@ bool launch_gemm_dma64(gnn_mlp *h, int cls, const GemmParams &p) {
     if (h->env_f32_dma_off || p.M % 64 || p.N % 64 || p.K % GemmF32DmaDepth<64>::BK) return false;
     constexpr size_t lds = gemm_f32_dma_lds_bytes<64, 64, 3>();
     auto kern = gemm_f32_dma_kernel<64, 64, A_KC, B_KC, EPI, 4, 3>;
-    static bool opted_in = false; // more than 64 KB of dynamic LDS needs the opt-in, once per instantiation
-    if (!opted_in) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            if (h->launch_error == hipSuccess) h->launch_error = hipGetLastError();
-        }
-        opted_in = true;
-    }
+    static bool opted_in[kMaxOptInDevices] = {}; // (per instantiation, per device)
+    opt_in_dynamic_lds(h, kern, lds, opted_in);
     launch_timed(h, cls, kern, dim3(p.N / 64, p.M / 64), dim3(512), lds, GNN_GEMM_HEAD_ARGS(p), p);
     return true;
 }

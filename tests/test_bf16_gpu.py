@@ -194,3 +194,43 @@ def test_bf16_dma_form_equals_register_staged(gnn, monkeypatch, dims, B):
         b.gradientStep(X, 0.0125, 0.9, False, expected=Y)
     assert np.array_equal(a.get_weights(), b.get_weights())
     assert np.array_equal(a.get_momentum(), b.get_momentum())
+
+
+@pytest.mark.parametrize("dims,B", [([784, 1024, 1024, 1024, 10], 256), ([200, 96, 40, 7], 50)])
+def test_bf16_gradients_of_all_layers_in_one_launch(gnn, monkeypatch, dims, B):
+    """A net whose gradient (+ update) products are a few hundred tiles each (BASELINE configs[4]: 208 + 256 + 256 + 16) sends
+    them as ONE launch of gemm_bf16_group_kernel, after all backward-data products (which read W before any update);
+    GNN_MLP_BF16_GROUP=0 keeps one launch per layer.  Same products, same order of sums: the same bits, in the gradients the
+    data-parallel hooks export and in weights, momentum and the bf16 shadow's effect (the next step's results) after fused
+    steps.  The second net (forced onto the per-layer path: its weights would fit the row-block kernel) has ragged tiles only."""
+    import os
+    if os.environ.get("GNN_MLP_PATH"):
+        pytest.skip("path forced by the environment")
+    if dims[0] == 200: monkeypatch.setenv("GNN_MLP_PATH", "generic")
+    X, Y = batch(dims, B, 77)
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn.DTYPE_BF16, max_batch=B)
+    monkeypatch.setenv("GNN_MLP_BF16_GROUP", "0")
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn.DTYPE_BF16, max_batch=B)
+    monkeypatch.delenv("GNN_MLP_BF16_GROUP")
+    w = a.get_weights() * (0.1 if dims[0] == 784 else 0.5)
+    a.set_weights(w); b.set_weights(w)
+    ga, gb = a.calculateWeightGradient(X, Y), b.calculateWeightGradient(X, Y)
+    for l in ga:
+        assert np.array_equal(ga[l], gb[l]), "layer %d" % l
+    if dims[0] == 200:   # (the small net also against the bf16-aware oracle; at configs[4]'s width a leaky-ReLU unit within a bf16
+        #                    rounding of zero flips its derivative between any two summation orders -- the per-layer launches,
+        #                    to which the grouped one is compared bit for bit above, are held against the oracle in the tests before)
+        Ws = np_oracle.split(a.get_weights(), dims)
+        gq = np_oracle.gradient_bf16(Ws, X.astype(np.float32).astype(np.float64), Y, LEAKY)
+        off = 0
+        for l in range(len(dims) - 1):
+            n = dims[l] * dims[l + 1]
+            ref_l = gq[off:off + n].reshape(dims[l], dims[l + 1]); off += n
+            assert np.abs(ga[l] - ref_l).max() <= 4e-3 * np.abs(ref_l).max() + 1e-7, "layer %d" % l
+    for s in range(3):
+        Xs, Ys = batch(dims, B, 80 + s)
+        a.gradientStep(Xs, 0.0125, 0.9, False, expected=Ys)
+        b.gradientStep(Xs, 0.0125, 0.9, False, expected=Ys)
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    assert np.array_equal(a.get_momentum(), b.get_momentum())
+    assert np.array_equal(a.propagate(X), b.propagate(X))
