@@ -1,6 +1,13 @@
 // gemm_probe.hip -- development harness (not shipped): times gemm_f32_kernel instantiations (tile, waves, register
 // stages) on the GEMM shapes of BASELINE configs[3] (4096-2048-2048-1024, 512 rows) and configs[4]
-// (784-1024-1024-1024-10, 256 rows).  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip -o tools/gemm_probe
+// (784-1024-1024-1024-10, 256 rows).  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip -o tools/_build/gemm_probe
+// Round 4's modes (tools/_build/gemm_probe <mode>; logs under profiles/r04/gemm_probe_*):
+//   30, 31  bf16 tile shapes; the bf16 gradient + update products          32, 38  what one K-slice of a split-K product costs (register-staged / DMA)
+//   33, 35  main-loop forms of gemm_bf16_kernel (LDS images, fragment depth, waves)   34  s_memtime stamps inside its loop (GEMM_PROBE_STAMPS=1)
+//   36      that loop compiled without its global loads / MFMAs / LDS reads / LDS writes (NSTG + 10 x ablation)
+//   37      gemm_bf16_dma_kernel: checked element by element against gemm_bf16_kernel, then timed      40  configs[4]'s bf16 products
+//   41      gemm_f32_kernel as shipped (build with -DGNN_F32_NO_LDS_WRITES for the loop without its LDS writes)
+//   42      gemm_f32_dma_kernel: checked against gemm_f32_kernel, then timed   43, 44  DMA form: K depth, a fourth image
 #define GNN_GEMM_BF16_STAMPS
 #include "../graph-neural-net_amd/csrc/gemm_wavek.h"
 #include "../graph-neural-net_amd/csrc/gemm_bf16.h"
