@@ -544,13 +544,22 @@ struct TailParams {
     int k_true;                   // its logical width
     int B, n_true;                // live rows, logical outputs
     int act;                      // inner activation (for f')
+    __bf16 *delta_out_b;          // BF16 form: the bf16 roundings of delta_out / delta_prev (same strides; may be null)
+    __bf16 *delta_prev_b;
 };
+
+// The value a bf16 GEMM operand has (GNN_DTYPE_BF16's contract: every product operand rounded to bf16, RNE -- the same conversion
+// that writes actb / Wb / deltab); a product of two such values is exact in f32, so the f32 MFMA below IS bf16 x bf16 -> f32.
+__device__ __forceinline__ float as_bf16_operand(float x) { return (float)(__bf16)x; }
 
 // grid = (row blocks, column splits): every workgroup of a row block forms the logits and the output rule (redundantly:
 // 16 x K x 16 MACs), split 0 stores them, and each split makes its share of delta_{L-2}'s columns -- 16 workgroups for a
 // 256-row batch became 128, and the column tiles' operands are requested together instead of one dependent round trip per
 // tile (784-1024^3-10 at 256 rows: 12.3 -> see profiles/r02).
-static __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
+// BF16: the two products take bf16-rounded operands (A_{L-2}, W_{L-2}, delta_{L-1}); f' is taken from the unrounded activation and
+// the bf16 copies of both deltas are written beside the f32 ones, as the bf16 per-layer path's other kernels do (gemm_bf16.h).
+template <bool BF16 = false>
+__global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
     constexpr int NW = 8, MAXC = 8, RLD = 20;
     __shared__ __attribute__((aligned(16))) float red[NW * 16 * RLD];
     __shared__ __attribute__((aligned(16))) float dl[16 * RLD];
@@ -573,6 +582,11 @@ static __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
                 a[i] = *reinterpret_cast<const float4 *>(arow + c * 16);
                 const float *w = wcol + (size_t)(c * 16) * 16;
                 b[i][0] = w[0]; b[i][1] = w[16]; b[i][2] = w[32]; b[i][3] = w[48];
+                if constexpr (BF16) {
+                    a[i].x = as_bf16_operand(a[i].x); a[i].y = as_bf16_operand(a[i].y); a[i].z = as_bf16_operand(a[i].z); a[i].w = as_bf16_operand(a[i].w);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) b[i][j] = as_bf16_operand(b[i][j]);
+                }
             } else {
                 a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 b[i][0] = b[i][1] = b[i][2] = b[i][3] = 0.f;
@@ -646,6 +660,13 @@ static __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
         const bool writer = blockIdx.y == 0;
         if (p.prob && writer) *reinterpret_cast<f32x4 *>(p.prob + (size_t)row * 16 + q * 4) = pr;
         if (p.delta_out && writer) *reinterpret_cast<f32x4 *>(p.delta_out + (size_t)row * 16 + q * 4) = dd;
+        if constexpr (BF16) {
+            typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+            const bf16x4_t db = {(__bf16)dd[0], (__bf16)dd[1], (__bf16)dd[2], (__bf16)dd[3]};
+            if (p.delta_out_b && writer) *reinterpret_cast<bf16x4_t *>(p.delta_out_b + (size_t)row * 16 + q * 4) = db;
+#pragma unroll
+            for (int j = 0; j < 4; j++) dd[j] = (float)db[j]; // the backward product's operand
+        }
         *reinterpret_cast<f32x4 *>(&dl[m * RLD + q * 4]) = dd;
         if (has_nan) best = 0;
         if (q == 0 && writer) {
@@ -669,6 +690,10 @@ static __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
             const int nt = base + i * NW;
             const int n = (nt < nt_end ? nt : base) * 16 + fr; // (a tile past the end re-reads the first: never used)
             wb[i] = *reinterpret_cast<const f32x4 *>(p.W + (size_t)n * 16 + 4 * fq); // W[n][4fq..4fq+3]
+            if constexpr (BF16) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) wb[i][j] = as_bf16_operand(wb[i][j]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; r++) av[i][r] = p.A[(size_t)(m0 + fq * 4 + r) * p.lda + n];
         }
@@ -684,7 +709,9 @@ static __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
             for (int r = 0; r < 4; r++) {
                 const int row = m0 + fq * 4 + r;
                 const bool live = row < p.B && n < p.k_true;
-                p.delta_prev[(size_t)row * p.ldp + n] = live ? c[r] * act_prime_from_a(p.act, av[i][r]) : 0.f;
+                const float dv = live ? c[r] * act_prime_from_a(p.act, av[i][r]) : 0.f;
+                p.delta_prev[(size_t)row * p.ldp + n] = dv;
+                if constexpr (BF16) { if (p.delta_prev_b) p.delta_prev_b[(size_t)row * p.ldp + n] = (__bf16)dv; }
             }
         }
     }

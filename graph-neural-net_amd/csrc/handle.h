@@ -300,8 +300,8 @@ void fused_gradient(gnn_mlp *h, const float *a0, int B, bool fused_update, float
 void launch_tail(gnn_mlp *h, const float *a0, const float *y, int B, bool backward, bool want_prob, bool want_loss, bool want_label);
 
 // ---- launch_bf16.hip ---------------------------------------------------------------------------
-void forward_bf16(gnn_mlp *h, const __bf16 *a0b, int B);
-void backward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool fused_update, float step_over_b, float momentum);
+void forward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool stop_before_last = false);
+void backward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool fused_update, float step_over_b, float momentum, bool have_tail = false);
 void to_bf16(gnn_mlp *h, const float *src, __bf16 *dst, size_t n);
 
 // ---- launch_small.hip: the row-block kernel and the tile-owner kernel ----------------------------

@@ -87,10 +87,10 @@ void launch_gemm_bf16(gnn_mlp *h, int cls, const GemmBf16Params &p) {
 }
 
 // ---- bf16 mode: forward / backward over the bf16 operand copies -------------------------------------
-void forward_bf16(gnn_mlp *h, const __bf16 *a0b, int B) {
+void forward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool stop_before_last) {
     const int B_pad = pad_up(B);
     const __bf16 *in = a0b;
-    for (int l = 1; l < h->L; l++) {
+    for (int l = 1; l < h->L - (stop_before_last ? 1 : 0); l++) {
         GemmBf16Params p{};
         p.A = in; p.lda = h->ld[l - 1];
         p.B = h->Wb + h->w_off[l - 1]; p.ldb = h->ld[l];
@@ -129,12 +129,13 @@ bool gradients_in_one_launch(const gnn_mlp *h) {
     return tiles <= 2048;
 }
 
-void backward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool fused_update, float step_over_b, float momentum) {
+// have_tail: delta_{L-2} (and its bf16 copy) came from tail_kernel<true>
+void backward_bf16(gnn_mlp *h, const __bf16 *a0b, int B, bool fused_update, float step_over_b, float momentum, bool have_tail) {
     const int B_pad = pad_up(B);
     const bool grouped = gradients_in_one_launch(h);
     GemmBf16Group grp{};
     for (int l = h->L - 2; l >= 0; l--) {
-        if (l >= 1) { // delta_l = (delta_{l+1} . W_l^T) * f'(z_l)   -- before W_l is touched
+        if (l >= 1 && !(have_tail && l == h->L - 2)) { // delta_l = (delta_{l+1} . W_l^T) * f'(z_l)   -- before W_l is touched
             GemmBf16Params p{};
             p.A = h->deltab[l + 1]; p.lda = h->ld[l + 1];
             p.B = h->Wb + h->w_off[l]; p.ldb = h->ld[l + 1];

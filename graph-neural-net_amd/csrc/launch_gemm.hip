@@ -286,7 +286,13 @@ void launch_tail(gnn_mlp *h, const float *a0, const float *y, int B, bool backwa
     const int row_blocks = pad_up(B) / 16, k16 = t.K / 16;
     int splits = 1;
     if (t.delta_prev) splits = std::max(1, std::min({8, 128 / row_blocks, k16 / 8}));
-    launch_timed(h, -1, tail_kernel, dim3(row_blocks, splits), dim3(512), 0, t);
+    if (h->dtype == GNN_DTYPE_BF16) {
+        t.delta_out_b = backward ? h->deltab[Lm] : nullptr;
+        t.delta_prev_b = (backward && Lm >= 2) ? h->deltab[Lm - 1] : nullptr;
+        launch_timed(h, -1, tail_kernel<true>, dim3(row_blocks, splits), dim3(512), 0, t);
+        return;
+    }
+    launch_timed(h, -1, tail_kernel<false>, dim3(row_blocks, splits), dim3(512), 0, t);
 }
 
 } // namespace host

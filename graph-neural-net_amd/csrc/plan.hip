@@ -223,7 +223,7 @@ HybridChoice hybrid_choice(const gnn_mlp *h, int B) {
 
 // Nets with at most 16 outputs, off the row-block path: last layer + output rule (+ delta_{L-2}) in one launch
 bool use_tail(const gnn_mlp *h) {
-    return !h->env_tail_off && h->dtype == GNN_DTYPE_F32 && h->out_kind == GNN_OUT_SOFTMAX_CE && h->ld[h->L - 1] == 16;
+    return !h->env_tail_off && h->out_kind == GNN_OUT_SOFTMAX_CE && h->ld[h->L - 1] == 16; // (both dtypes: tail_kernel<BF16>)
 }
 
 // bf16 twin of an A_0 row pointer: the staging rows or the resident dataset
@@ -235,8 +235,10 @@ const __bf16 *a0_bf16(const gnn_mlp *h, const float *a0) {
 // the three shapes every entry point is made of
 void do_forward(gnn_mlp *h, const float *a0, const float *y, int B, bool want_prob, bool want_loss, bool want_label) {
     if (h->dtype == GNN_DTYPE_BF16) {
-        forward_bf16(h, a0_bf16(h, a0), B);
-        run_output(h, y, B, want_prob, false, want_loss, want_label);
+        const bool tail = use_tail(h);
+        forward_bf16(h, a0_bf16(h, a0), B, tail);
+        if (tail) launch_tail(h, a0, y, B, false, want_prob, want_loss, want_label);
+        else run_output(h, y, B, want_prob, false, want_loss, want_label);
         return;
     }
     // Blocks of thousands of rows (evaluation over a whole data set, gnn_mlp_count_hits_range): the row-block kernel re-reads every
@@ -261,9 +263,11 @@ void do_gradient(gnn_mlp *h, const float *a0, const float *y, int B, bool fused_
     h->have_next = false;
     if (h->dtype == GNN_DTYPE_BF16) {
         const __bf16 *a0b = a0_bf16(h, a0);
-        forward_bf16(h, a0b, B);
-        run_output(h, y, B, false, true, false, false);
-        backward_bf16(h, a0b, B, fused_update, step_over_b, momentum);
+        const bool tail = use_tail(h); // last layer + output rule + delta_{L-2} in one launch (three of the twelve of configs[4])
+        forward_bf16(h, a0b, B, tail);
+        if (tail) launch_tail(h, a0, y, B, true, false, false, false);
+        else run_output(h, y, B, false, true, false, false);
+        backward_bf16(h, a0b, B, fused_update, step_over_b, momentum, tail);
         return;
     }
     if (h->mid4) {

@@ -234,3 +234,47 @@ def test_bf16_gradients_of_all_layers_in_one_launch(gnn, monkeypatch, dims, B):
     assert np.array_equal(a.get_weights(), b.get_weights())
     assert np.array_equal(a.get_momentum(), b.get_momentum())
     assert np.array_equal(a.propagate(X), b.propagate(X))
+
+
+@pytest.mark.parametrize("dims,B", [([784, 1024, 1024, 1024, 10], 256), ([300, 10], 40), ([200, 96, 40, 7], 50)])
+def test_bf16_tail_kernel_against_three_launches(gnn, monkeypatch, dims, B):
+    """bf16 nets with at most 16 outputs on the per-layer path end their forward pass in tail_kernel<true>: the last layer's
+    product on bf16-rounded operands (exact in the f32 MFMA), the output rule, and delta_{L-2} from the bf16-rounded output delta,
+    one launch instead of GEMM + output kernel + GEMM (GNN_MLP_TAIL=0).  The two forms add the same products in different
+    orders, and a delta within an f32 rounding of a bf16 boundary may round the other way: compared to 2e-3 of each layer's
+    largest gradient, probabilities to 1e-5, and the tail form against the bf16-aware oracle where the net is small enough for
+    leaky ReLU's derivative not to flip (see the test above)."""
+    import os
+    if os.environ.get("GNN_MLP_PATH"):
+        pytest.skip("path forced by the environment")
+    if dims[0] in (200, 300): monkeypatch.setenv("GNN_MLP_PATH", "generic")
+    X, Y = batch(dims, B, 91)
+    a = gnn.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn.DTYPE_BF16, max_batch=B)
+    monkeypatch.setenv("GNN_MLP_TAIL", "0")
+    b = gnn.SoftmaxCrossEntropyNeuralNet(dims, dtype=gnn.DTYPE_BF16, max_batch=B)
+    monkeypatch.delenv("GNN_MLP_TAIL")
+    w = a.get_weights() * (0.1 if dims[0] == 784 else 0.5)
+    a.set_weights(w); b.set_weights(w)
+    pa, pb = a.propagate(X), b.propagate(X)
+    assert np.abs(pa - pb).max() <= 1e-5
+    assert np.array_equal(a.argmax(X), b.argmax(X)) or (np.sort(pa, axis=1)[:, -1] - np.sort(pa, axis=1)[:, -2]).min() < 1e-4
+    la, lb = a.calculateLoss(X, Y), b.calculateLoss(X, Y)
+    assert np.all(np.abs(la - lb) <= 1e-4 * np.abs(lb) + 1e-5)
+    ga, gb = a.calculateWeightGradient(X, Y), b.calculateWeightGradient(X, Y)
+    for l in ga:
+        assert np.abs(ga[l] - gb[l]).max() <= 2e-3 * np.abs(gb[l]).max() + 1e-9, "layer %d" % l
+    if dims[0] != 784:
+        Ws = np_oracle.split(a.get_weights(), dims)
+        X32 = X.astype(np.float32).astype(np.float64)
+        _, _, out = np_oracle.forward_bf16(Ws, X32, LEAKY)
+        assert np.abs(pa - out).max() <= 5e-3
+        gq = np_oracle.gradient_bf16(Ws, X32, Y, LEAKY)
+        off = 0
+        for l in range(len(dims) - 1):
+            n = dims[l] * dims[l + 1]
+            ref_l = gq[off:off + n].reshape(dims[l], dims[l + 1]); off += n
+            assert np.abs(ga[l] - ref_l).max() <= 4e-3 * np.abs(ref_l).max() + 1e-7, "layer %d" % l
+    for s in range(2):
+        a.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+        b.gradientStep(X, 0.0125, 0.9, False, expected=Y)
+    assert np.abs(a.get_weights() - b.get_weights()).max() <= 2e-4
