@@ -601,6 +601,29 @@ __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i][3], acc, 0, 0, 0);
         }
     }
+    // The operands of this wave's first delta_{L-2} tiles (W rows, the activations f' is taken from) depend on nothing computed
+    // here: requested NOW, their round trip runs under the reduction, the barrier and the output rule instead of after them.
+    constexpr int TB = 4;
+    const int nt_begin = (int)((long)blockIdx.y * k16 / gridDim.y), nt_end = (int)((long)(blockIdx.y + 1) * k16 / gridDim.y);
+    f32x4 wb[TB];
+    float av[TB][4];
+    auto load_tiles = [&](int base) {
+#pragma unroll
+        for (int i = 0; i < TB; i++) {
+            const int nt = base + i * NW;
+            const int n = (nt < nt_end ? nt : base) * 16 + fr; // (a tile past the end re-reads the first: never used)
+            wb[i] = *reinterpret_cast<const f32x4 *>(p.W + (size_t)n * 16 + 4 * fq); // W[n][4fq..4fq+3]
+            if constexpr (BF16) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) wb[i][j] = as_bf16_operand(wb[i][j]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) av[i][r] = p.A[(size_t)(m0 + fq * 4 + r) * p.lda + n];
+        }
+    };
+    const bool have_first = p.delta_prev && nt_begin + wave < nt_end; // (wave-uniform)
+    if (have_first) load_tiles(nt_begin + wave);
+
     const f32x4 acc = acc0 + acc1;
 #pragma unroll
     for (int r = 0; r < 4; r++) red[(wave * 16 + fq * 4 + r) * RLD + fr] = acc[r];
@@ -678,25 +701,10 @@ __global__ __launch_bounds__(512) void tail_kernel(TailParams p) {
     __syncthreads();
 
     // ---- delta_{L-2}[16 x K]: this split's 16-column tiles, dealt to the waves; k = 4*fq + i for the i-th MFMA on both
-    // operands.  Up to TB tiles per trip, every operand of the trip requested before the first is used.
-    constexpr int TB = 4;
+    // operands.  Up to TB tiles per trip, every operand of the trip requested before the first is used (the first trip's: above).
     const f32x4 da = *reinterpret_cast<const f32x4 *>(&dl[fr * RLD + 4 * fq]); // delta_{L-1}[m = fr][4fq..4fq+3]
-    const int nt_begin = (int)((long)blockIdx.y * k16 / gridDim.y), nt_end = (int)((long)(blockIdx.y + 1) * k16 / gridDim.y);
     for (int base = nt_begin + wave; base < nt_end; base += NW * TB) {
-        f32x4 wb[TB];
-        float av[TB][4];
-#pragma unroll
-        for (int i = 0; i < TB; i++) {
-            const int nt = base + i * NW;
-            const int n = (nt < nt_end ? nt : base) * 16 + fr; // (a tile past the end re-reads the first: never used)
-            wb[i] = *reinterpret_cast<const f32x4 *>(p.W + (size_t)n * 16 + 4 * fq); // W[n][4fq..4fq+3]
-            if constexpr (BF16) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) wb[i][j] = as_bf16_operand(wb[i][j]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) av[i][r] = p.A[(size_t)(m0 + fq * 4 + r) * p.lda + n];
-        }
+        if (base != nt_begin + wave) load_tiles(base);
 #pragma unroll
         for (int i = 0; i < TB; i++) {
             const int nt = base + i * NW;
